@@ -1,0 +1,39 @@
+# Top-level build.  Everything is built in-tree so the artefacts travel with the
+# snapshot to the GPU box (they are git-ignored, not gpurun-ignored).
+#
+#   make lib      libnvk_paged_attn.so: HIP kernels + C ABI, gfx950 only
+#   make oracle   the CPU checker (oracle/, test infrastructure)
+#   make ref      the reference's own headers behind a shim (only where /root/reference exists)
+#   make all      all of the above
+
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := nano_vllm_amd/csrc
+LIB     := nano_vllm_amd/libnvk_paged_attn.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -I$(CSRC) \
+            -Wall -Wno-unused-function -fno-gpu-rdc
+
+.PHONY: all lib oracle ref clean asm
+all: lib oracle ref
+
+lib: $(LIB)
+
+$(LIB): $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_kernels.hip.h $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_internal.h include/nvk_paged_attn.h
+	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_block_manager.cpp
+
+# device assembly + register/occupancy report for the kernels (not needed to run)
+asm:
+	mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) -save-temps=obj -c \
+	   -Rpass-analysis=kernel-resource-usage -o build/nvk_paged_attn.o $(CSRC)/nvk_paged_attn.hip 2> build/resource_usage.txt
+
+oracle:
+	$(MAKE) -C oracle oracle
+
+ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -f $(LIB)
+	rm -rf build
+	$(MAKE) -C oracle clean

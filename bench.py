@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- paged-attention decode on MI355X: achieved HBM GB/s and layer-call tokens/s.
+
+    python bench.py --gpus N --steps K --warmup W [--workload config2|config3|config4|5a|5b]
+                    [--mode auto|single|split] [--chunk T] [--no-cpu]
+
+A "step" is one layer-call: one new token for every sequence of the batch in
+one layer.  At N=1 the default workload is BASELINE.json
+configs[1] (64 seqs x 2K ctx, uniform block tables, fp32 KV, 32q/8kv heads x
+128).  For N>1 the path is sequence-sharded: every rank owns a private pool and
+its own batch of that shape, there is no data-path collective, and the job's
+throughput is the sum over ranks over the slowest rank's time (weak scaling).
+
+Inputs are resident in HBM before the timed region (the pool is filled by a
+device kernel; q / block tables / lengths are device tensors).  Rank 0 prints
+ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_workload(name):
+    from nano_vllm_amd import workloads as wl
+
+    if name == "config2":
+        return wl.config2()
+    if name == "config3":
+        return wl.config3()
+    if name == "config4":
+        return wl.config4()
+    if name == "5a":
+        return wl.config5a(512)
+    if name == "5b":
+        return wl.config5b(512)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(work, cores):
+    """The reference's CPU attention timed on this host (rank 0, N=1 only).
+
+    kind "reference": the reference's own header compiled with its own flags
+    (oracle/_ref/libnvk_ref_fast.so); kind "port": our C restatement with the
+    same flags when that library did not travel.  The whole workload is run
+    when it is small enough, otherwise a bounded sample of its sequences."""
+    import oracle_lib as ol
+    from concurrent.futures import ThreadPoolExecutor
+    from nano_vllm_amd import workloads as wl
+
+    g = work.geom
+    # bound the sample: about 64 K context tokens per core-second at these flags
+    budget_tokens = 2_500_000
+    order = np.arange(work.num_seqs)
+    take, tok = [], 0
+    for s in order:
+        if tok + int(work.ctx_lens[s]) > budget_tokens and take:
+            break
+        take.append(int(s))
+        tok += int(work.ctx_lens[s])
+    k_host, v_host, tabs, ctx = wl.host_blocks_for(work, take)
+    q = work.q()[take]
+    sample_bytes = int(2 * ctx.astype(np.int64).sum() * g.n_kv_heads * g.head_dim * 4
+                       + 2 * len(take) * g.n_heads * g.head_dim * 4
+                       + ((ctx.astype(np.int64) + g.block_size - 1) // g.block_size).sum() * 4)
+    out = np.empty_like(q)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+
+    ref = ol.load_fast_ref()
+    port = ol.load_fast_oracle()
+    if ref is not None:
+        kind = "reference"
+
+        def run(lo, hi, scratch):
+            ref.ref_paged_attention_batch(p(out), p(q), p(k_host), p(v_host), p(tabs), int(tabs.shape[1]), p(ctx),
+                                          lo, hi, p(scratch), g.block_size, g.head_dim, g.n_heads, g.n_kv_heads)
+    elif port is not None:
+        kind = "port"
+
+        def run(lo, hi, scratch):
+            for s in range(lo, hi):
+                port.oracle_paged_attention(p(out[s]), p(q[s]), p(k_host), p(v_host), p(tabs[s]), p(scratch),
+                                            int(ctx[s]), g.block_size, g.head_dim, g.n_heads, g.n_kv_heads)
+    else:
+        return None, None
+
+    max_ctx = int(ctx.max())
+    n = len(take)
+
+    def timed(n_threads):
+        scr = [np.empty(g.n_heads * max_ctx, np.float32) for _ in range(n_threads)]
+        bounds = np.linspace(0, n, n_threads + 1).astype(int)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            if n_threads == 1:
+                run(0, n, scr[0])
+            else:
+                with ThreadPoolExecutor(n_threads) as ex:
+                    list(ex.map(lambda i: run(int(bounds[i]), int(bounds[i + 1]), scr[i]), range(n_threads)))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+
+    sample = (f"{n} of {work.num_seqs} sequences of {work.name} ({int(ctx.sum())} context tokens), "
+              f"best of 3 passes, -O3 -ffast-math -march=x86-64-v3")
+    t1 = timed(1)
+    one = {"value": round(sample_bytes / t1 / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": kind, "sample": sample,
+           "ms_per_layer_call": round(t1 * 1e3 * work.num_seqs / n, 2)}
+    many = None
+    if cores > 1 and n >= 2:
+        nt = min(cores, n)
+        tn = timed(nt)
+        many = {"value": round(sample_bytes / tn / 1e9, 3), "unit": "GB/s", "cores": nt, "kind": kind,
+                "sample": sample, "ms_per_layer_call": round(tn * 1e3 * work.num_seqs / n, 2)}
+    return one, many
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--mode", default="auto", choices=["auto", "single", "split"])
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import nano_vllm_amd as nv
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if nv.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    work = make_workload(args.workload)
+    g = work.geom
+    flags = {"auto": nv.AUTO, "single": nv.SINGLE_PASS, "split": nv.SPLIT_K}[args.mode]
+
+    pool = nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=local_rank)
+    pool.fill_uniform(0, 1, 2)
+    q = torch.from_numpy(work.q()).to(dev)
+    tabs = torch.from_numpy(work.block_tables).to(dev)
+    ctx = torch.from_numpy(work.ctx_lens).to(dev)
+    out = torch.empty_like(q)
+    torch.cuda.synchronize()
+
+    def run(warmup, iters):
+        return nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
+                               flags, args.chunk, warmup, iters)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    run(args.warmup, 0)  # W untimed steps (also sizes the split-K workspace)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    step_ms, attn_ms = run(0, args.steps)  # EXACTLY K steps; HIP events on the launch stream inside
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier()
+
+    if world > 1:
+        t = torch.tensor([wall, step_ms, attn_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, step_ms, attn_ms = (float(x) for x in t.tolist())
+
+    if rank == 0:
+        nbytes = work.algorithmic_bytes()  # per rank, per layer-call
+        ms_per_step = wall * 1e3 / args.steps
+        value = nbytes * world / (ms_per_step * 1e-3) / 1e9
+        achieved = nbytes / (attn_ms * 1e-3) / 1e9
+        line = {
+            "metric": "paged_attn_decode_achieved_hbm_GBps",
+            "value": round(value, 1),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": work.name, "num_seqs_per_gpu": work.num_seqs, "total_ctx_tokens_per_gpu":
+                       work.total_tokens, "n_heads": g.n_heads, "n_kv_heads": g.n_kv_heads, "head_dim": g.head_dim,
+                       "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode,
+                       "parallelism": f"sequence-sharded x{world}, no collective"},
+            "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
+            "tokens_per_s": round(work.num_seqs * world / (ms_per_step * 1e-3), 1),
+            "tokens_per_s_32_layer_model": round(work.num_seqs * world / (ms_per_step * 1e-3) / 32.0, 1),
+            "event_ms_per_step": round(step_ms, 4),
+            "roofline": {"bound": "hbm", "kernel": "nvk_decode_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "kernel_ms": round(attn_ms, 4), "algorithmic_bytes": nbytes},
+        }
+        if world == 1 and not args.no_cpu:
+            cores = min(16, os.cpu_count() or 1)
+            one, many = cpu_baseline(work, cores)
+            if one is not None:
+                line["cpu_baseline"] = one
+            if many is not None:
+                line["cpu_baseline_all_cores"] = many
+        print(json.dumps(line), flush=True)
+
+    pool.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/* nvk_paged_attn.h -- C ABI of libnvk_paged_attn.so
+ *
+ * MI355X (gfx950) paged-attention decode behind nano-vllm's attention
+ * interface.  Plain pointers and sizes only; no C++ or torch types cross this
+ * boundary and no exception ever leaves the library.  Every function returns
+ * an int status (NVK_OK == 0, negative on failure) unless noted; the message
+ * for the calling thread's last failure is nvk_last_error().
+ *
+ * "ref:" comments name the reference interface each entry point replaces
+ * (paths relative to the reference tree, aerlabsAI/nano-vllm @ 2026-01-30).
+ *
+ * Threading: a pool is thread-compatible (external synchronisation per pool);
+ * distinct pools (one per GPU) may be driven from different host threads.
+ * nvk_bm_* is safe exactly where the reference's BlockManager is: the
+ * *_for_request / *_safe entry points lock, the plain ones do not.
+ */
+#ifndef NVK_PAGED_ATTN_H
+#define NVK_PAGED_ATTN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+#define NVK_OK 0
+#define NVK_ERR_INVALID_ARG (-1) /* null pointer, negative size, geometry the pool does not have */
+#define NVK_ERR_OOM (-2)         /* device allocation failed, or no free KV blocks               */
+#define NVK_ERR_HIP (-3)         /* a HIP runtime call failed; text in nvk_last_error()          */
+#define NVK_ERR_BAD_BLOCK (-4)   /* block id outside [0, num_blocks)                             */
+#define NVK_ERR_NO_DEVICE (-5)   /* no gfx950 device visible                                     */
+#define NVK_ERR_UNBOUND (-6)     /* nvk_paged_attention() called with no pool bound/stageable    */
+
+/* decode flags */
+#define NVK_DECODE_AUTO 0        /* library picks chunking from the batch shape      */
+#define NVK_DECODE_SINGLE_PASS 1 /* one chunk per sequence, no workspace, no merge   */
+#define NVK_DECODE_SPLIT_K 2     /* flash-decoding: chunk_tokens per workgroup+merge */
+
+/* pointer kinds for the *_ex entry points */
+#define NVK_PTR_HOST 0
+#define NVK_PTR_DEVICE 1
+
+typedef struct nvk_pool          nvk_pool;          /* device-resident paged KV pool */
+typedef struct nvk_block_manager nvk_block_manager; /* host-side block allocator     */
+
+const char *nvk_version(void);
+/* thread-local, never NULL; valid until the thread's next failing call */
+const char *nvk_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int nvk_device_count(void);
+
+/* ------------------------------------------------------------ KV pool ----
+ * ref: Config paged fields        include/core/model.hpp:33-36
+ *      RunState::paged_*_cache    include/core/model.hpp:94-97
+ *      initialize_paged_attention include/core/model.hpp:249-277
+ * Layout in HBM is the reference's, unchanged, so block tables built by a
+ * reference-equivalent BlockManager index it directly:
+ *   K and V each [n_layers, num_blocks, block_size, n_kv_heads, head_dim] fp32.
+ * Zero-initialised like the reference's std::vector::resize. */
+int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads, int head_dim, int device,
+                    nvk_pool **out_pool);
+int nvk_pool_destroy(nvk_pool *pool);
+/* out6 = {n_layers, num_blocks, block_size, n_kv_heads, head_dim, device} */
+int nvk_pool_geometry(const nvk_pool *pool, int *out6);
+/* device base addresses of one layer's K and V slabs (for callers that fill
+ * the pool with their own kernels, e.g. a fused RoPE+append) */
+int nvk_pool_layer_ptrs(const nvk_pool *pool, int layer, void **k_dev, void **v_dev);
+/* the pool's own HIP stream (hipStream_t) */
+int nvk_pool_stream(const nvk_pool *pool, void **stream);
+int nvk_pool_synchronize(nvk_pool *pool);
+
+/* KV append of one token row, host pointers.
+ * ref: the two memcpys in LlamaModel::forward, include/core/model.hpp:190-207.
+ * k_row / v_row: [n_kv_heads * head_dim] floats. */
+int nvk_pool_append(nvk_pool *pool, int layer, int physical_block, int block_offset, const float *k_row,
+                    const float *v_row);
+
+/* Batched KV append: one new token per sequence, scattered by a HIP kernel.
+ * Row s goes to block_tables[s][positions[s] / block_size], offset
+ * positions[s] % block_size (ref: include/core/model.hpp:190-199, applied per
+ * sequence).  k_rows/v_rows: [num_seqs, n_kv_heads*head_dim]; block_tables:
+ * row-padded [num_seqs, max_blocks]; ptr_kind says where all four live. */
+int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *k_rows, const float *v_rows,
+                          const int *block_tables, int max_blocks, const int *positions, int ptr_kind);
+
+/* Whole-block transfers, host pointers, [block_size, n_kv_heads, head_dim] floats each. */
+int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const float *k_block,
+                          const float *v_block);
+int nvk_pool_download_block(nvk_pool *pool, int layer, int physical_block, float *k_block, float *v_block);
+
+/* The KV gather on its own (bit-exactness check of the addressing at
+ * include/core/attention.hpp:109-115,145-151): copies, with the same HIP
+ * address arithmetic the decode kernel uses, the num_tokens rows of kv_head
+ * that block_table addresses into k_out/v_out [num_tokens, head_dim] (host). */
+int nvk_pool_gather(nvk_pool *pool, int layer, const int *block_table, int num_tokens, int kv_head, float *k_out,
+                    float *v_out);
+
+/* Synthetic fill on the device: element i of the layer's K slab becomes
+ * value(seed_k, i), of the V slab value(seed_v, i), value() being the
+ * counter-based generator of SURVEY.md 8d / oracle_fill_uniform(). */
+int nvk_pool_fill_uniform(nvk_pool *pool, int layer, uint64_t seed_k, uint64_t seed_v);
+
+/* ------------------------------------------------------ decode attention --
+ * Batched paged-attention decode: one new token for each of num_seqs
+ * sequences in one layer (a "layer-call").  Per sequence the result equals
+ * ref: Attention::paged_attention, include/core/attention.hpp:82-159, called
+ * as in LlamaModel::attention, include/core/model.hpp:393-416.
+ *   q, out        [num_seqs, n_heads, head_dim] fp32
+ *   block_tables  [num_seqs, max_blocks] int32, row-padded; entries beyond
+ *                 ceil(ctx_lens[s]/block_size) are ignored
+ *   ctx_lens      [num_seqs] tokens to attend to (pos + 1); 0 gives a zero row
+ *   flags         NVK_DECODE_*; chunk_tokens only for NVK_DECODE_SPLIT_K
+ *                 (rounded to the kernel's step; 0 = library default)
+ * Host-pointer form: validates every used table entry against num_blocks
+ * (NVK_ERR_BAD_BLOCK), stages inputs, runs, copies out back, synchronises. */
+int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q, const int *block_tables,
+               int max_blocks, const int *ctx_lens, float *out, int flags, int chunk_tokens);
+
+/* Device-pointer form: asynchronous on `stream` (hipStream_t; NULL = the
+ * pool's stream).  max_ctx >= every ctx_lens[s] sizes the launch (the lengths
+ * themselves are read on the device).  Table entries are clamped to
+ * [0, num_blocks) on the device rather than validated. */
+int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                      const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
+                      float *out_dev, int flags, int chunk_tokens, void *stream);
+
+/* Pre-size the split-K workspace so later nvk_decode_device calls of up to
+ * this shape do not allocate. */
+int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int chunk_tokens);
+
+/* HIP-event timing of the device form, on the pool's stream (the stream the
+ * kernels are launched on): `warmup` untimed layer-calls, a stream
+ * synchronise, then ONE timed region of `iters` layer-calls.
+ *   total_ms  region time / iters (attention kernel + merge kernel + gaps)
+ *   attn_ms   mean over the same region of the attention kernel's own
+ *             duration, from an event pair around each of its launches
+ * Either may be NULL; iters == 0 only warms up.  Returns after the region has
+ * finished on the device. */
+int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                     const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
+                     float *out_dev, int flags, int chunk_tokens, int warmup, int iters, float *total_ms,
+                     float *attn_ms);
+
+/* Drop-in for the reference function, same eleven arguments, host pointers.
+ * ref: Attention::paged_attention, include/core/attention.hpp:82-92.
+ *  - With a pool bound on this thread (nvk_bind_pool), key_cache/value_cache
+ *    are not dereferenced: the bound layer of the device pool is the cache
+ *    (its geometry must match block_size/head_dim/n_kv_heads).
+ *  - With no pool bound, key_cache/value_cache are the reference's host slabs
+ *    for one layer: the blocks block_table names are staged to the device for
+ *    this call (correct, PCIe-bound; for tests and first bring-up).
+ *  att_scores is accepted and ignored (may be NULL).  Returns a status where
+ *  the reference returns void. */
+int nvk_paged_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
+                        const int *block_table, float *att_scores, int num_tokens, int block_size, int head_dim,
+                        int n_heads, int n_kv_heads);
+/* Bind (pool, layer) as this thread's cache for nvk_paged_attention; pool NULL unbinds.
+ * ref: the layer slicing in LlamaModel::attention, include/core/model.hpp:400-403. */
+int nvk_bind_pool(nvk_pool *pool, int layer);
+
+/* ---------------------------------------------------------- BlockManager --
+ * Host-side allocator returning the same ids in the same order as
+ * ref: BlockManager, include/scheduler/block_manager.hpp:14-283
+ * (lowest free index first), in O(log64 n) instead of a linear scan.
+ * Where the reference throws std::runtime_error the status is returned
+ * instead and the state is left as the reference leaves it. */
+int  nvk_bm_create(int num_blocks, int block_size, nvk_block_manager **out_bm); /* ref :17-24  */
+void nvk_bm_destroy(nvk_block_manager *bm);
+int  nvk_bm_allocate_block(nvk_block_manager *bm);                /* id, or -1 when full. ref :28-44 */
+int  nvk_bm_free_block(nvk_block_manager *bm, int block_id);      /* NVK_ERR_BAD_BLOCK where ref throws. ref :48-62 */
+/* count written to ids (capacity cap), or NVK_ERR_OOM where ref throws "Out of memory". ref :67-92 */
+int  nvk_bm_allocate_sequence(nvk_block_manager *bm, int num_tokens, int *ids, int cap);
+int  nvk_bm_free_sequence(nvk_block_manager *bm, const int *ids, int n); /* ref :96-101 */
+int  nvk_bm_num_free_blocks(const nvk_block_manager *bm);               /* ref :107 */
+int  nvk_bm_num_blocks(const nvk_block_manager *bm);                    /* ref :110 */
+int  nvk_bm_block_size(const nvk_block_manager *bm);                    /* ref :113 */
+int  nvk_bm_is_free(const nvk_block_manager *bm, int block_id);         /* ref :116-121 */
+float nvk_bm_utilization(const nvk_block_manager *bm);                  /* ref :124 */
+/* per-request, mutex-guarded, non-throwing. ref :132-216 */
+int  nvk_bm_allocate_for_request(nvk_block_manager *bm, int request_id, int num_tokens, int *ids, int cap);
+int  nvk_bm_allocate_block_for_request(nvk_block_manager *bm, int request_id);
+void nvk_bm_free_request(nvk_block_manager *bm, int request_id);
+int  nvk_bm_get_request_blocks(nvk_block_manager *bm, int request_id, int *ids, int cap);
+int  nvk_bm_get_request_block_count(nvk_block_manager *bm, int request_id);
+int  nvk_bm_num_active_requests(nvk_block_manager *bm);
+int  nvk_bm_allocate_block_safe(nvk_block_manager *bm);
+void nvk_bm_free_block_safe(nvk_block_manager *bm, int block_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVK_PAGED_ATTN_H */

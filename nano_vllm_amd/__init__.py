@@ -1,0 +1,18 @@
+"""nano_vllm_amd: MI355X-native paged-attention decode behind nano-vllm's attention interface.
+
+The package is a thin host layer over ``libnvk_paged_attn.so`` (hand-written
+gfx950 HIP kernels + a C ABI, ``include/nvk_paged_attn.h``).  Importing it
+without the built library raises ImportError: there is no CPU fallback.
+(The directory is ``nano_vllm_amd`` rather than ``nano-vllm_amd`` only because a
+hyphen is not importable in Python.)
+"""
+from . import _capi
+from ._capi import NvkError, device_count, version
+from .attention import AUTO, SINGLE_PASS, SPLIT_K, bind_pool, decode, decode_bench, decode_device, paged_attention
+from .block_manager import BlockManager
+from .kv_pool import PagedKVPool
+
+__all__ = [
+    "AUTO", "SINGLE_PASS", "SPLIT_K", "BlockManager", "NvkError", "PagedKVPool", "bind_pool", "decode",
+    "decode_bench", "decode_device", "device_count", "paged_attention", "version",
+]

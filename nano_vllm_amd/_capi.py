@@ -1,0 +1,123 @@
+"""ctypes binding of libnvk_paged_attn.so (include/nvk_paged_attn.h).
+
+The library is the product: if it is missing this module raises at import
+time, loudly, and nothing in the package falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnvk_paged_attn.so")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_OOM = -2
+ERR_HIP = -3
+ERR_BAD_BLOCK = -4
+ERR_NO_DEVICE = -5
+ERR_UNBOUND = -6
+
+DECODE_AUTO = 0
+DECODE_SINGLE_PASS = 1
+DECODE_SPLIT_K = 2
+
+PTR_HOST = 0
+PTR_DEVICE = 1
+
+
+class NvkError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[nvk {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make lib` (hipcc --offload-arch=gfx950). "
+        "nano_vllm_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/nvk_paged_attn.h declares
+SIGNATURES = {
+    "nvk_version": (C.c_char_p, []),
+    "nvk_last_error": (C.c_char_p, []),
+    "nvk_device_count": (C.c_int, []),
+    "nvk_pool_create": (C.c_int, [C.c_int] * 6 + [C.POINTER(_vp)]),
+    "nvk_pool_destroy": (C.c_int, [_vp]),
+    "nvk_pool_geometry": (C.c_int, [_vp, _i]),
+    "nvk_pool_layer_ptrs": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "nvk_pool_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "nvk_pool_synchronize": (C.c_int, [_vp]),
+    "nvk_pool_append": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "nvk_pool_append_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "nvk_pool_upload_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "nvk_pool_download_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "nvk_pool_gather": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "nvk_pool_fill_uniform": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64]),
+    "nvk_pool_reserve_workspace": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nvk_decode": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int]),
+    "nvk_decode_device": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
+    ),
+    "nvk_decode_bench": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+         _f, _f],
+    ),
+    "nvk_paged_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nvk_bind_pool": (C.c_int, [_vp, C.c_int]),
+    "nvk_bm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "nvk_bm_destroy": (None, [_vp]),
+    "nvk_bm_allocate_block": (C.c_int, [_vp]),
+    "nvk_bm_free_block": (C.c_int, [_vp, C.c_int]),
+    "nvk_bm_allocate_sequence": (C.c_int, [_vp, C.c_int, _i, C.c_int]),
+    "nvk_bm_free_sequence": (C.c_int, [_vp, _i, C.c_int]),
+    "nvk_bm_num_free_blocks": (C.c_int, [_vp]),
+    "nvk_bm_num_blocks": (C.c_int, [_vp]),
+    "nvk_bm_block_size": (C.c_int, [_vp]),
+    "nvk_bm_is_free": (C.c_int, [_vp, C.c_int]),
+    "nvk_bm_utilization": (C.c_float, [_vp]),
+    "nvk_bm_allocate_for_request": (C.c_int, [_vp, C.c_int, C.c_int, _i, C.c_int]),
+    "nvk_bm_allocate_block_for_request": (C.c_int, [_vp, C.c_int]),
+    "nvk_bm_free_request": (None, [_vp, C.c_int]),
+    "nvk_bm_get_request_blocks": (C.c_int, [_vp, C.c_int, _i, C.c_int]),
+    "nvk_bm_get_request_block_count": (C.c_int, [_vp, C.c_int]),
+    "nvk_bm_num_active_requests": (C.c_int, [_vp]),
+    "nvk_bm_allocate_block_safe": (C.c_int, [_vp]),
+    "nvk_bm_free_block_safe": (None, [_vp, C.c_int]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library disagree
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return lib.nvk_last_error().decode("utf-8", "replace")
+
+
+def check(code: int) -> int:
+    if code < 0:
+        raise NvkError(code, last_error())
+    return code
+
+
+def version() -> str:
+    return lib.nvk_version().decode()
+
+
+def device_count() -> int:
+    return int(lib.nvk_device_count())

@@ -1,0 +1,457 @@
+// nvk_kernels.hip.h -- gfx950 (CDNA4, wave64) device code for paged-attention decode.
+//
+// What the reference computes per sequence (include/core/attention.hpp:82-159):
+//   out[h,:] = sum_t softmax_t(q[h].K[t,kv(h)] / sqrt(hd)) * V[t,kv(h)],  kv(h) = h / (n_heads/n_kv_heads)
+// with K/V rows addressed through the block table (:109-115, :145-151):
+//   row(t) = block_table[t / block_size] * block_size + t % block_size
+//   &K[t, kvh, 0] = key_cache + (row(t) * n_kv_heads + kvh) * head_dim
+//
+// How it is mapped to the machine:
+//   * work item = (sequence, token chunk); one workgroup per item; wave w of
+//     the workgroup owns kv-head (blockIdx.z*waves + w) and its QPK q-heads,
+//     so the waves of a workgroup together stream whole, contiguous token rows.
+//   * inside a wave the 64 lanes are 4 token slots x 16 lanes; a slot's 16
+//     lanes cover one (token, kv-head) row with VPL float4 each (lane r owns
+//     dims 64*j + 4*r .. +3).  One wave load instruction therefore fetches
+//     four tokens x 256 contiguous bytes = 8 full 128-B lines, every byte used.
+//   * K/V go straight from HBM to VGPRs (no reuse, so no LDS round trip), two
+//     token quads per step, double buffered: 8-16 KiB in flight per wave.
+//   * QK^T: 4*VPL FMAs per (token, q-head) then a 16-lane all-reduce done with
+//     four DPP adds (quad_perm, quad_perm, row_half_mirror, row_mirror); no
+//     LDS, no cross-row traffic in the loop.
+//   * online softmax state (m, l) and the PV accumulator live per token slot
+//     in registers, in the exp2 domain (q is pre-scaled by log2(e)/sqrt(hd)).
+//   * the chunk's slice of the block table is staged once per workgroup in LDS.
+//   * at the end the four slots are merged with two xor-shuffles, and either
+//     the normalised row is written (one chunk per sequence) or an
+//     unnormalised partial (m, l, o) goes to the split-K workspace, merged by
+//     nvk_merge_kernel (flash-decoding).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nvk {
+
+constexpr int   kStepTokens = 8;        // tokens per wave per pipeline step (2 quads)
+constexpr float kNegBig     = -1.0e30f; // running-max seed: finite, so exp2(m - m) never sees inf - inf
+// The reference seeds its max with -1e10 (attention.hpp:126); in the exp2
+// domain that floor is -1e10 * log2(e).
+constexpr float kRefMaxFloorLog2 = -1.0e10f * 1.44269504088896340736f;
+
+struct DecodeParams
+{
+    const float *k_layer; // one layer of the pool: [num_blocks, block_size, n_kv_heads, head_dim]
+    const float *v_layer;
+    const float *q;            // [num_seqs, n_heads, head_dim]
+    const int   *block_tables; // [num_seqs, max_blocks]
+    const int   *ctx_lens;     // [num_seqs]
+    float       *out;          // [num_seqs, n_heads, head_dim]
+    float       *ws_o;         // [num_seqs, max_chunks, n_heads, head_dim]  unnormalised partial outputs
+    float       *ws_ml;        // [num_seqs, max_chunks, n_heads, 2]         (running max, running sum)
+    int          max_blocks;
+    int          num_blocks;
+    int          block_size;
+    int          bs_shift; // log2(block_size), or -1 when block_size is not a power of two
+    int          n_kv_heads;
+    int          n_heads;
+    int          kv_mul; // n_heads / n_kv_heads
+    int          head_dim;
+    int          chunk_tokens; // multiple of kStepTokens
+    int          max_chunks;   // 1: the kernel writes `out` itself
+    float        q_scale;      // log2(e) / sqrt(head_dim)
+};
+
+// ---- address arithmetic shared by decode, gather and append ---------------
+__device__ __forceinline__ int token_block(int tok, int block_size, int bs_shift)
+{
+    return bs_shift >= 0 ? (tok >> bs_shift) : (tok / block_size);
+}
+__device__ __forceinline__ int token_offset(int tok, int blk, int block_size, int bs_shift)
+{
+    return bs_shift >= 0 ? (tok & (block_size - 1)) : (tok - blk * block_size);
+}
+// float index of element 0 of (physical block, offset, kv head) inside a layer slab
+__device__ __forceinline__ int64_t row_float_index(int physical_block, int block_offset, int kv_head,
+                                                   int block_size, int n_kv_heads, int head_dim)
+{
+    return (((int64_t)physical_block * block_size + block_offset) * n_kv_heads + kv_head) * (int64_t)head_dim;
+}
+// A table entry the reference would treat as undefined behaviour must not fault the GPU.
+__device__ __forceinline__ int clamp_block(int id, int num_blocks)
+{
+    return (int)min((unsigned)id, (unsigned)(num_blocks - 1));
+}
+
+// ---- wave-level helpers ---------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_move(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+// Sum over the 16 lanes of a DPP row; every lane of the row gets the same bits.
+__device__ __forceinline__ float row16_allsum(float x)
+{
+    x += dpp_move<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);  // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x); // row_half_mirror
+    x += dpp_move<0x140>(x); // row_mirror
+    return x;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b, float acc)
+{
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+template <int VPL> struct KVTile
+{
+    float4 k[2][VPL];
+    float4 v[2][VPL];
+};
+
+// ---- the decode kernel ----------------------------------------------------
+// VPL   float4 per lane per row (head_dim <= 64*VPL)
+// QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.z also walks kv_mul/QPK)
+// FULL  head_dim == 64*VPL, so no lane is idle and no load needs a predicate
+template <int VPL, int QPK, bool FULL>
+__global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice
+
+    const int seq   = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int ctx   = p.ctx_lens[seq];
+    const int t0    = chunk * p.chunk_tokens;
+
+    const int lane   = threadIdx.x & 63;
+    const int wave   = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int slot   = lane >> 4; // which token of a quad
+    const int r      = lane & 15; // which 16 B of a 256-B row piece
+
+    // blockIdx.z enumerates (kv-head group, q sub-group); waves enumerate kv-heads in the group
+    const int qsplit = p.kv_mul / QPK;
+    const int zq     = blockIdx.z % qsplit;
+    const int kvh    = (blockIdx.z / qsplit) * nwaves + wave;
+    const bool live  = kvh < p.n_kv_heads;
+    const int  qh0   = kvh * p.kv_mul + zq * QPK; // first q-head of this wave
+
+    const int hd = p.head_dim;
+    bool      act[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; j++)
+        act[j] = FULL || (64 * j + 4 * r < hd);
+
+    if (ctx <= 0) {
+        // the reference zeroes `out` before anything else (attention.hpp:98)
+        if (p.max_chunks == 1 && chunk == 0 && live && slot == 0) {
+#pragma unroll
+            for (int h = 0; h < QPK; h++)
+#pragma unroll
+                for (int j = 0; j < VPL; j++)
+                    if (act[j])
+                        *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j
+                                                    + 4 * r) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    if (t0 >= ctx)
+        return; // whole workgroup: this sequence has fewer chunks than the grid is wide
+
+    const int t1   = min(t0 + p.chunk_tokens, ctx);
+    const int blk0 = token_block(t0, p.block_size, p.bs_shift);
+    const int blk1 = token_block(t1 - 1, p.block_size, p.bs_shift);
+    for (int i = threadIdx.x; i <= blk1 - blk0; i += blockDim.x)
+        s_tab[i] = clamp_block(p.block_tables[(int64_t)seq * p.max_blocks + blk0 + i], p.num_blocks);
+    __syncthreads();
+    if (!live)
+        return; // no barrier after this point
+
+    // q for this wave's q-heads, pre-scaled into the exp2 domain
+    float4 qv[QPK][VPL];
+#pragma unroll
+    for (int h = 0; h < QPK; h++)
+#pragma unroll
+        for (int j = 0; j < VPL; j++) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act[j])
+                t = *reinterpret_cast<const float4 *>(p.q + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j
+                                                      + 4 * r);
+            qv[h][j] = make_float4(t.x * p.q_scale, t.y * p.q_scale, t.z * p.q_scale, t.w * p.q_scale);
+        }
+
+    float  m[QPK], l[QPK];
+    float4 o[QPK][VPL];
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        m[h] = kNegBig;
+        l[h] = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; j++)
+            o[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    const int lane_col = kvh * hd + 4 * r; // float offset of this lane inside a token row
+    const int row_len  = p.n_kv_heads * hd;
+
+    auto load_tile = [&](KVTile<VPL> &T, int ts) {
+        int64_t at[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int tok = min(ts + 4 * i + slot, t1 - 1); // past-the-end lanes re-read the last row
+            const int blk = token_block(tok, p.block_size, p.bs_shift);
+            const int off = token_offset(tok, blk, p.block_size, p.bs_shift);
+            const int pb  = s_tab[blk - blk0];
+            at[i]         = ((int64_t)pb * p.block_size + off) * row_len + lane_col;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < VPL; j++) {
+                T.k[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act[j])
+                    T.k[i][j] = *reinterpret_cast<const float4 *>(p.k_layer + at[i] + 64 * j);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < VPL; j++) {
+                T.v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act[j])
+                    T.v[i][j] = *reinterpret_cast<const float4 *>(p.v_layer + at[i] + 64 * j);
+            }
+    };
+
+    auto consume_tile = [&](const KVTile<VPL> &T, int ts) {
+        float s[2][QPK];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const bool in_range = ts + 4 * i + slot < t1;
+#pragma unroll
+            for (int h = 0; h < QPK; h++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < VPL; j++)
+                    acc = dot4(qv[h][j], T.k[i][j], acc);
+                acc     = row16_allsum(acc);
+                s[i][h] = in_range ? acc : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < QPK; h++) {
+            const float mn    = fmaxf(m[h], fmaxf(s[0][h], s[1][h]));
+            const float alpha = fast_exp2(m[h] - mn);
+            const float p0    = fast_exp2(s[0][h] - mn);
+            const float p1    = fast_exp2(s[1][h] - mn);
+            m[h]              = mn;
+            l[h]              = fmaf(l[h], alpha, p0 + p1);
+#pragma unroll
+            for (int j = 0; j < VPL; j++) {
+                float4 a = o[h][j];
+                a.x      = fmaf(a.x, alpha, fmaf(p0, T.v[0][j].x, p1 * T.v[1][j].x));
+                a.y      = fmaf(a.y, alpha, fmaf(p0, T.v[0][j].y, p1 * T.v[1][j].y));
+                a.z      = fmaf(a.z, alpha, fmaf(p0, T.v[0][j].z, p1 * T.v[1][j].z));
+                a.w      = fmaf(a.w, alpha, fmaf(p0, T.v[0][j].w, p1 * T.v[1][j].w));
+                o[h][j]  = a;
+            }
+        }
+    };
+
+    // two named tiles, hand-unrolled by two, so no register copies and no runtime-indexed arrays
+    KVTile<VPL> ta, tb;
+    int         ts = t0;
+    load_tile(ta, ts);
+    for (;;) {
+        if (ts + kStepTokens < t1)
+            load_tile(tb, ts + kStepTokens);
+        consume_tile(ta, ts);
+        ts += kStepTokens;
+        if (ts >= t1)
+            break;
+        if (ts + kStepTokens < t1)
+            load_tile(ta, ts + kStepTokens);
+        consume_tile(tb, ts);
+        ts += kStepTokens;
+        if (ts >= t1)
+            break;
+    }
+
+    // merge the four token slots of the wave (lanes 16 and 32 apart)
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        float mw = fmaxf(m[h], __shfl_xor(m[h], 16));
+        mw       = fmaxf(mw, __shfl_xor(mw, 32));
+        const float f = fast_exp2(m[h] - mw);
+        float       lw = l[h] * f;
+        lw += __shfl_xor(lw, 16);
+        lw += __shfl_xor(lw, 32);
+        m[h] = mw;
+        l[h] = lw;
+#pragma unroll
+        for (int j = 0; j < VPL; j++) {
+            float4 a = o[h][j];
+            a.x *= f, a.y *= f, a.z *= f, a.w *= f;
+            a.x += __shfl_xor(a.x, 16), a.y += __shfl_xor(a.y, 16), a.z += __shfl_xor(a.z, 16),
+                a.w += __shfl_xor(a.w, 16);
+            a.x += __shfl_xor(a.x, 32), a.y += __shfl_xor(a.y, 32), a.z += __shfl_xor(a.z, 32),
+                a.w += __shfl_xor(a.w, 32);
+            o[h][j] = a;
+        }
+    }
+
+    if (slot != 0)
+        return;
+
+    if (p.max_chunks == 1) {
+#pragma unroll
+        for (int h = 0; h < QPK; h++) {
+            // reference: max_val = max(-1e10, scores) (attention.hpp:126-130); a no-op unless every score is below it
+            const float mf  = fmaxf(m[h], kRefMaxFloorLog2);
+            const float f   = fast_exp2(m[h] - mf);
+            const float inv = f / (l[h] * f);
+#pragma unroll
+            for (int j = 0; j < VPL; j++)
+                if (act[j])
+                    *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
+                        make_float4(o[h][j].x * inv, o[h][j].y * inv, o[h][j].z * inv, o[h][j].w * inv);
+        }
+    }
+    else {
+        const int64_t item = (int64_t)seq * p.max_chunks + chunk;
+#pragma unroll
+        for (int h = 0; h < QPK; h++) {
+#pragma unroll
+            for (int j = 0; j < VPL; j++)
+                if (act[j])
+                    *reinterpret_cast<float4 *>(p.ws_o + (item * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
+                        o[h][j];
+            if (r == 0)
+                *reinterpret_cast<float2 *>(p.ws_ml + (item * p.n_heads + qh0 + h) * 2) = make_float2(m[h], l[h]);
+        }
+    }
+}
+
+// ---- split-K merge (flash-decoding combine) ---------------------------------
+// One thread per (sequence, q-head, float4 of head_dim): log-sum-exp merge of
+// the sequence's chunk partials, then the reference's normalisation.
+__global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict__ ws_o,
+                                                        const float *__restrict__ ws_ml,
+                                                        const int *__restrict__ ctx_lens, float *__restrict__ out,
+                                                        int n_heads, int head_dim, int chunk_tokens,
+                                                        int max_chunks)
+{
+    const int seq     = blockIdx.y;
+    const int vec_row = head_dim >> 2; // float4 per head
+    const int idx     = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_heads * vec_row)
+        return;
+    const int head = idx / vec_row;
+    const int vec  = idx - head * vec_row;
+
+    const int ctx = ctx_lens[seq];
+    const int nch = ctx <= 0 ? 0 : min((ctx + chunk_tokens - 1) / chunk_tokens, max_chunks);
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float *dst = out + ((int64_t)seq * n_heads + head) * head_dim + 4 * vec;
+    if (nch == 0) {
+        *reinterpret_cast<float4 *>(dst) = acc;
+        return;
+    }
+    const float *ml = ws_ml + ((int64_t)seq * max_chunks * n_heads + head) * 2;
+    const float *po = ws_o + ((int64_t)seq * max_chunks * n_heads + head) * head_dim + 4 * vec;
+
+    float top = kRefMaxFloorLog2; // the reference's -1e10 floor, see nvk_decode_kernel
+    for (int c = 0; c < nch; c++)
+        top = fmaxf(top, ml[(int64_t)c * n_heads * 2]);
+    float denom = 0.f;
+    for (int c = 0; c < nch; c++) {
+        const float2 s = *reinterpret_cast<const float2 *>(ml + (int64_t)c * n_heads * 2);
+        const float  f = fast_exp2(s.x - top);
+        const float4 a = *reinterpret_cast<const float4 *>(po + (int64_t)c * n_heads * head_dim);
+        denom          = fmaf(s.y, f, denom);
+        acc.x          = fmaf(a.x, f, acc.x);
+        acc.y          = fmaf(a.y, f, acc.y);
+        acc.z          = fmaf(a.z, f, acc.z);
+        acc.w          = fmaf(a.w, f, acc.w);
+    }
+    const float inv                  = 1.0f / denom;
+    *reinterpret_cast<float4 *>(dst) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+// ---- KV gather on its own (addressing check) --------------------------------
+// grid.x = tokens; copies K and V rows of one kv-head to [num_tokens, head_dim].
+__global__ void nvk_gather_kernel(const float *__restrict__ k_layer, const float *__restrict__ v_layer,
+                                  const int *__restrict__ block_table, int num_tokens, int kv_head, int num_blocks,
+                                  int block_size, int bs_shift, int n_kv_heads, int head_dim,
+                                  float *__restrict__ k_out, float *__restrict__ v_out)
+{
+    const int tok = blockIdx.x;
+    if (tok >= num_tokens)
+        return;
+    const int     blk = token_block(tok, block_size, bs_shift);
+    const int     off = token_offset(tok, blk, block_size, bs_shift);
+    const int     pb  = clamp_block(block_table[blk], num_blocks);
+    const int64_t at  = row_float_index(pb, off, kv_head, block_size, n_kv_heads, head_dim);
+    for (int d = threadIdx.x; d < head_dim; d += blockDim.x) {
+        k_out[(int64_t)tok * head_dim + d] = k_layer[at + d];
+        v_out[(int64_t)tok * head_dim + d] = v_layer[at + d];
+    }
+}
+
+// ---- batched KV append (reference: model.hpp:190-207, once per sequence) -----
+// grid.x = sequences; a workgroup copies one K row and one V row of
+// n_kv_heads*head_dim floats to the slot positions[s] of its sequence.
+__global__ void nvk_append_kernel(float *__restrict__ k_layer, float *__restrict__ v_layer,
+                                  const float *__restrict__ k_rows, const float *__restrict__ v_rows,
+                                  const int *__restrict__ block_tables, int max_blocks,
+                                  const int *__restrict__ positions, int num_blocks, int block_size, int bs_shift,
+                                  int row_len)
+{
+    const int seq = blockIdx.x;
+    const int pos = positions[seq];
+    if (pos < 0)
+        return;
+    const int     blk = token_block(pos, block_size, bs_shift);
+    const int     off = token_offset(pos, blk, block_size, bs_shift);
+    const int     pb  = clamp_block(block_tables[(int64_t)seq * max_blocks + blk], num_blocks);
+    const int64_t at  = ((int64_t)pb * block_size + off) * row_len;
+    for (int i = threadIdx.x * 4; i < row_len; i += blockDim.x * 4) { // row_len % 4 == 0 (checked on the host)
+        *reinterpret_cast<float4 *>(k_layer + at + i) =
+            *reinterpret_cast<const float4 *>(k_rows + (int64_t)seq * row_len + i);
+        *reinterpret_cast<float4 *>(v_layer + at + i) =
+            *reinterpret_cast<const float4 *>(v_rows + (int64_t)seq * row_len + i);
+    }
+}
+
+// ---- synthetic fill: the counter-based generator of SURVEY.md 8d -------------
+__device__ __forceinline__ float uniform_from_counter(uint64_t seed, uint64_t index)
+{
+    uint64_t x = (seed ^ index) + 0x9E3779B97F4A7C15ULL;
+    x          = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x          = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return (float)(x >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+}
+
+__global__ void nvk_fill_kernel(float *__restrict__ dst, uint64_t seed, uint64_t count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < count; i += stride) {
+        if (i + 4 <= count) {
+            *reinterpret_cast<float4 *>(dst + i) =
+                make_float4(uniform_from_counter(seed, i), uniform_from_counter(seed, i + 1),
+                            uniform_from_counter(seed, i + 2), uniform_from_counter(seed, i + 3));
+        }
+        else {
+            for (uint64_t k = i; k < count; k++)
+                dst[k] = uniform_from_counter(seed, k);
+        }
+    }
+}
+
+} // namespace nvk

@@ -1,0 +1,868 @@
+// nvk_paged_attn.hip -- host side of libnvk_paged_attn.so: the device-resident
+// paged KV pool, kernel dispatch and the C ABI declared in include/nvk_paged_attn.h.
+// Device code is in nvk_kernels.hip.h.  gfx950 only; there is no CPU fallback:
+// every compute entry point fails with NVK_ERR_NO_DEVICE / NVK_ERR_HIP when no
+// MI355X is visible.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "nvk_internal.h"
+#include "nvk_kernels.hip.h"
+
+#define NVK_VERSION_STRING "nvk_paged_attn 0.1.0 (gfx950)"
+
+// ------------------------------------------------------------------ errors
+namespace nvk {
+
+static thread_local char g_last_error[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+} // namespace nvk
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return nvk::fail(e__ == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "%s failed: %s (%s:%d)", #expr,  \
+                             hipGetErrorString(e__), __FILE__, __LINE__);                                              \
+    } while (0)
+
+namespace {
+
+// Makes `device` current for the scope and restores the caller's device after.
+struct DeviceScope
+{
+    int  previous = -1;
+    bool ok       = false;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&previous) != hipSuccess)
+            previous = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (previous >= 0)
+            (void)hipSetDevice(previous);
+    }
+};
+
+int log2_exact(int v)
+{
+    if (v <= 0 || (v & (v - 1)))
+        return -1;
+    int s = 0;
+    while ((1 << s) < v)
+        s++;
+    return s;
+}
+
+int round_up(int v, int to) { return (v + to - 1) / to * to; }
+
+} // namespace
+
+// -------------------------------------------------------------------- pool
+struct nvk_pool
+{
+    int    n_layers = 0, num_blocks = 0, block_size = 0, n_kv_heads = 0, head_dim = 0, device = 0;
+    int    bs_shift     = -1;
+    size_t layer_floats = 0; // num_blocks * block_size * n_kv_heads * head_dim
+    float *k = nullptr, *v = nullptr;
+    hipStream_t stream = nullptr;
+    int         num_cus = 256;
+
+    // split-K workspace (grown on demand, reused across calls)
+    float *ws_o = nullptr, *ws_ml = nullptr;
+    size_t ws_o_floats = 0, ws_ml_floats = 0;
+
+    // staging for the host-pointer entry points
+    char  *stage     = nullptr;
+    size_t stage_cap = 0;
+
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+
+    float *k_layer(int layer) const { return k + (size_t)layer * layer_floats; }
+    float *v_layer(int layer) const { return v + (size_t)layer * layer_floats; }
+    int    row_len() const { return n_kv_heads * head_dim; }
+};
+
+namespace {
+
+int ensure_stage(nvk_pool *pool, size_t bytes)
+{
+    if (bytes <= pool->stage_cap)
+        return NVK_OK;
+    if (pool->stage) {
+        HIP_TRY(hipStreamSynchronize(pool->stream));
+        HIP_TRY(hipFree(pool->stage));
+        pool->stage     = nullptr;
+        pool->stage_cap = 0;
+    }
+    const size_t want = std::max(bytes, (size_t)1 << 20);
+    HIP_TRY(hipMalloc(&pool->stage, want));
+    pool->stage_cap = want;
+    return NVK_OK;
+}
+
+int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
+{
+    if (o_floats > pool->ws_o_floats) {
+        if (pool->ws_o) {
+            HIP_TRY(hipStreamSynchronize(pool->stream));
+            HIP_TRY(hipFree(pool->ws_o));
+            pool->ws_o        = nullptr;
+            pool->ws_o_floats = 0;
+        }
+        HIP_TRY(hipMalloc(&pool->ws_o, o_floats * sizeof(float)));
+        pool->ws_o_floats = o_floats;
+    }
+    if (ml_floats > pool->ws_ml_floats) {
+        if (pool->ws_ml) {
+            HIP_TRY(hipStreamSynchronize(pool->stream));
+            HIP_TRY(hipFree(pool->ws_ml));
+            pool->ws_ml        = nullptr;
+            pool->ws_ml_floats = 0;
+        }
+        HIP_TRY(hipMalloc(&pool->ws_ml, ml_floats * sizeof(float)));
+        pool->ws_ml_floats = ml_floats;
+    }
+    return NVK_OK;
+}
+
+int check_pool_layer(const nvk_pool *pool, int layer, const char *who)
+{
+    if (!pool)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "%s: null pool", who);
+    if (layer < 0 || layer >= pool->n_layers)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "%s: layer %d outside [0,%d)", who, layer, pool->n_layers);
+    return NVK_OK;
+}
+
+// ------------------------------------------------------------ launch plan
+struct LaunchPlan
+{
+    int chunk_tokens = 0; // multiple of kStepTokens
+    int max_chunks   = 1;
+    int waves        = 1; // kv-heads per workgroup
+    int kv_groups    = 1;
+    int qpk          = 1; // q-heads per wave
+    int vpl          = 1;
+    bool full        = false;
+    size_t lds_bytes = 0;
+};
+
+constexpr int kMaxTableSliceEntries = 8192; // 32 KiB of LDS per workgroup at most
+
+int make_plan(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens,
+              LaunchPlan *plan)
+{
+    const int hd = pool->head_dim;
+    if (n_heads <= 0 || n_heads % pool->n_kv_heads != 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "n_heads=%d is not a positive multiple of n_kv_heads=%d", n_heads,
+                         pool->n_kv_heads);
+    if (hd % 4 != 0 || hd > 256)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "head_dim=%d unsupported (need a multiple of 4, at most 256)", hd);
+    const int kv_mul = n_heads / pool->n_kv_heads;
+    plan->vpl        = hd <= 64 ? 1 : (hd <= 128 ? 2 : 4);
+    plan->full       = hd == 64 * plan->vpl;
+    plan->qpk        = kv_mul % 4 == 0 ? 4 : (kv_mul % 2 == 0 ? 2 : 1);
+    if (plan->vpl == 4 && plan->qpk == 4)
+        plan->qpk = 2; // 4 q-heads x 16 floats of q and o per lane would spill
+    plan->waves      = std::min(pool->n_kv_heads, 8);
+    plan->kv_groups  = (pool->n_kv_heads + plan->waves - 1) / plan->waves;
+
+    const int step    = nvk::kStepTokens;
+    const int ctx_cap = round_up(std::max(max_ctx, 1), step);
+    // a workgroup stages its chunk's table slice in LDS: bound the chunk by that
+    const long long slice_cap = (long long)kMaxTableSliceEntries * pool->block_size / step * step;
+
+    long long chunk = 0;
+    if (flags == NVK_DECODE_SINGLE_PASS) {
+        chunk = ctx_cap;
+    }
+    else if (flags == NVK_DECODE_SPLIT_K && chunk_tokens > 0) {
+        chunk = round_up(chunk_tokens, step);
+    }
+    else {
+        // AUTO (and SPLIT_K with no size): enough workgroups to fill every CU a few
+        // times over, but chunks no shorter than 128 tokens so the per-chunk
+        // prologue/epilogue stays small against the streaming loop.
+        const long long target_wgs = (long long)pool->num_cus * 8;
+        const long long per_chunk  = std::max<long long>(1, (long long)num_seqs * plan->kv_groups * (kv_mul / plan->qpk));
+        long long       chunks_per_seq = std::max<long long>(1, target_wgs / per_chunk);
+        chunk                          = round_up((int)std::max<long long>(128, (ctx_cap + chunks_per_seq - 1) / chunks_per_seq), step);
+    }
+    chunk = std::min<long long>(chunk, ctx_cap);
+    chunk = std::min<long long>(chunk, slice_cap);
+    chunk = std::max<long long>(chunk, step);
+    plan->chunk_tokens = (int)chunk;
+    plan->max_chunks   = (ctx_cap + plan->chunk_tokens - 1) / plan->chunk_tokens;
+    plan->lds_bytes    = ((size_t)plan->chunk_tokens / pool->block_size + 2) * sizeof(int);
+    return NVK_OK;
+}
+
+template <int VPL, int QPK> hipError_t launch_decode_full(bool full, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                                         const nvk::DecodeParams &p)
+{
+    if (full)
+        hipLaunchKernelGGL((nvk::nvk_decode_kernel<VPL, QPK, true>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((nvk::nvk_decode_kernel<VPL, QPK, false>), grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                                const nvk::DecodeParams &p)
+{
+    switch (qpk) {
+    case 4:
+        if constexpr (VPL < 4) // <4,4> would spill; make_plan never asks for it
+            return launch_decode_full<VPL, 4>(full, grid, block, lds, stream, p);
+        else
+            return hipErrorInvalidValue;
+    case 2: return launch_decode_full<VPL, 2>(full, grid, block, lds, stream, p);
+    default: return launch_decode_full<VPL, 1>(full, grid, block, lds, stream, p);
+    }
+}
+
+hipError_t launch_decode(const LaunchPlan &plan, dim3 grid, dim3 block, hipStream_t stream, const nvk::DecodeParams &p)
+{
+    switch (plan.vpl) {
+    case 1: return launch_decode_qpk<1>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
+    case 2: return launch_decode_qpk<2>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
+    default: return launch_decode_qpk<4>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
+    }
+}
+
+// Enqueue one layer-call on `stream`.  All pointers are device pointers.
+// ev_mid_a/ev_mid_b (optional) bracket the attention kernel alone.
+int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev, const int *tables_dev,
+                   int max_blocks, const int *ctx_dev, int max_ctx, float *out_dev, int flags, int chunk_tokens,
+                   hipStream_t stream, hipEvent_t ev_attn_begin, hipEvent_t ev_attn_end)
+{
+    if (num_seqs == 0)
+        return NVK_OK;
+    LaunchPlan plan;
+    int        rc = make_plan(pool, num_seqs, n_heads, max_ctx, flags, chunk_tokens, &plan);
+    if (rc != NVK_OK)
+        return rc;
+    if ((long long)max_blocks * pool->block_size < max_ctx)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "max_blocks=%d x block_size=%d cannot hold max_ctx=%d", max_blocks,
+                         pool->block_size, max_ctx);
+    if (num_seqs > 65535 * 1)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "num_seqs=%d exceeds the grid's y extent (65535)", num_seqs);
+
+    const int kv_mul = n_heads / pool->n_kv_heads;
+    if (plan.max_chunks > 1) {
+        rc = ensure_workspace(pool, (size_t)num_seqs * plan.max_chunks * n_heads * pool->head_dim,
+                              (size_t)num_seqs * plan.max_chunks * n_heads * 2);
+        if (rc != NVK_OK)
+            return rc;
+    }
+
+    nvk::DecodeParams p;
+    p.k_layer      = pool->k_layer(layer);
+    p.v_layer      = pool->v_layer(layer);
+    p.q            = q_dev;
+    p.block_tables = tables_dev;
+    p.ctx_lens     = ctx_dev;
+    p.out          = out_dev;
+    p.ws_o         = pool->ws_o;
+    p.ws_ml        = pool->ws_ml;
+    p.max_blocks   = max_blocks;
+    p.num_blocks   = pool->num_blocks;
+    p.block_size   = pool->block_size;
+    p.bs_shift     = pool->bs_shift;
+    p.n_kv_heads   = pool->n_kv_heads;
+    p.n_heads      = n_heads;
+    p.kv_mul       = kv_mul;
+    p.head_dim     = pool->head_dim;
+    p.chunk_tokens = plan.chunk_tokens;
+    p.max_chunks   = plan.max_chunks;
+    p.q_scale      = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
+
+    const dim3 grid((unsigned)plan.max_chunks, (unsigned)num_seqs, (unsigned)(plan.kv_groups * (kv_mul / plan.qpk)));
+    const dim3 block((unsigned)plan.waves * 64);
+    if (ev_attn_begin)
+        HIP_TRY(hipEventRecord(ev_attn_begin, stream));
+    HIP_TRY(launch_decode(plan, grid, block, stream, p));
+    if (ev_attn_end)
+        HIP_TRY(hipEventRecord(ev_attn_end, stream));
+
+    if (plan.max_chunks > 1) {
+        const int  vecs = n_heads * (pool->head_dim / 4);
+        const dim3 mgrid((unsigned)((vecs + 255) / 256), (unsigned)num_seqs);
+        hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml, ctx_dev, out_dev,
+                           n_heads, pool->head_dim, plan.chunk_tokens, plan.max_chunks);
+        HIP_TRY(hipGetLastError());
+    }
+    return NVK_OK;
+}
+
+// thread-local binding for the drop-in entry point
+thread_local nvk_pool *t_bound_pool  = nullptr;
+thread_local int       t_bound_layer = 0;
+// thread-local scratch pool for the unbound (host-slab) form of the drop-in
+thread_local nvk_pool *t_scratch_pool = nullptr;
+
+} // namespace
+
+extern "C" {
+
+const char *nvk_version(void) { return NVK_VERSION_STRING; }
+const char *nvk_last_error(void) { return nvk::g_last_error; }
+
+int nvk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads, int head_dim, int device,
+                    nvk_pool **out_pool)
+{
+    if (!out_pool)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_create: out_pool is null");
+    *out_pool = nullptr;
+    if (n_layers <= 0 || num_blocks <= 0 || block_size <= 0 || n_kv_heads <= 0 || head_dim <= 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_create: every dimension must be positive");
+    if (head_dim % 4 != 0 || head_dim > 256)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_create: head_dim=%d unsupported (multiple of 4, <= 256)",
+                         head_dim);
+    if ((long long)num_blocks * block_size > 0x7fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_create: num_blocks*block_size must fit in int32");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return nvk::fail(NVK_ERR_NO_DEVICE, "nvk_pool_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_create: device %d outside [0,%d)", device, ndev);
+
+    DeviceScope scope(device);
+    if (!scope.ok)
+        return nvk::fail(NVK_ERR_HIP, "nvk_pool_create: hipSetDevice(%d) failed", device);
+
+    nvk_pool *pool = new (std::nothrow) nvk_pool();
+    if (!pool)
+        return nvk::fail(NVK_ERR_OOM, "nvk_pool_create: host allocation failed");
+    pool->n_layers = n_layers, pool->num_blocks = num_blocks, pool->block_size = block_size;
+    pool->n_kv_heads = n_kv_heads, pool->head_dim = head_dim, pool->device = device;
+    pool->bs_shift     = log2_exact(block_size);
+    pool->layer_floats = (size_t)num_blocks * block_size * n_kv_heads * head_dim;
+
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        pool->num_cus = prop.multiProcessorCount;
+
+    const size_t bytes = pool->layer_floats * (size_t)n_layers * sizeof(float);
+    hipError_t   e     = hipMalloc(&pool->k, bytes);
+    if (e == hipSuccess)
+        e = hipMalloc(&pool->v, bytes);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreate(&pool->ev_a);
+    if (e == hipSuccess)
+        e = hipEventCreate(&pool->ev_b);
+    // zero like std::vector::resize in initialize_paged_attention (model.hpp:267-268)
+    if (e == hipSuccess)
+        e = hipMemsetAsync(pool->k, 0, bytes, pool->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(pool->v, 0, bytes, pool->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(pool->stream);
+    if (e != hipSuccess) {
+        const int code = nvk::fail(e == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP,
+                                   "nvk_pool_create: %s (2 x %zu bytes requested)", hipGetErrorString(e), bytes);
+        nvk_pool_destroy(pool);
+        return code;
+    }
+    *out_pool = pool;
+    return NVK_OK;
+}
+
+int nvk_pool_destroy(nvk_pool *pool)
+{
+    if (!pool)
+        return NVK_OK;
+    DeviceScope scope(pool->device);
+    if (t_bound_pool == pool)
+        t_bound_pool = nullptr;
+    if (pool->stream)
+        (void)hipStreamSynchronize(pool->stream);
+    if (pool->k)
+        (void)hipFree(pool->k);
+    if (pool->v)
+        (void)hipFree(pool->v);
+    if (pool->ws_o)
+        (void)hipFree(pool->ws_o);
+    if (pool->ws_ml)
+        (void)hipFree(pool->ws_ml);
+    if (pool->stage)
+        (void)hipFree(pool->stage);
+    if (pool->ev_a)
+        (void)hipEventDestroy(pool->ev_a);
+    if (pool->ev_b)
+        (void)hipEventDestroy(pool->ev_b);
+    if (pool->stream)
+        (void)hipStreamDestroy(pool->stream);
+    delete pool;
+    return NVK_OK;
+}
+
+int nvk_pool_geometry(const nvk_pool *pool, int *out6)
+{
+    if (!pool || !out6)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_geometry: null argument");
+    out6[0] = pool->n_layers, out6[1] = pool->num_blocks, out6[2] = pool->block_size;
+    out6[3] = pool->n_kv_heads, out6[4] = pool->head_dim, out6[5] = pool->device;
+    return NVK_OK;
+}
+
+int nvk_pool_layer_ptrs(const nvk_pool *pool, int layer, void **k_dev, void **v_dev)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_layer_ptrs");
+    if (rc != NVK_OK)
+        return rc;
+    if (k_dev)
+        *k_dev = pool->k_layer(layer);
+    if (v_dev)
+        *v_dev = pool->v_layer(layer);
+    return NVK_OK;
+}
+
+int nvk_pool_stream(const nvk_pool *pool, void **stream)
+{
+    if (!pool || !stream)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_stream: null argument");
+    *stream = (void *)pool->stream;
+    return NVK_OK;
+}
+
+int nvk_pool_synchronize(nvk_pool *pool)
+{
+    if (!pool)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_synchronize: null pool");
+    DeviceScope scope(pool->device);
+    HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_append(nvk_pool *pool, int layer, int physical_block, int block_offset, const float *k_row,
+                    const float *v_row)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_append");
+    if (rc != NVK_OK)
+        return rc;
+    if (!k_row || !v_row)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append: null row");
+    if (physical_block < 0 || physical_block >= pool->num_blocks)
+        return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_append: block %d outside [0,%d)", physical_block,
+                         pool->num_blocks);
+    if (block_offset < 0 || block_offset >= pool->block_size)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append: offset %d outside [0,%d)", block_offset,
+                         pool->block_size);
+    DeviceScope  scope(pool->device);
+    const size_t row = (size_t)pool->row_len();
+    const size_t at  = ((size_t)physical_block * pool->block_size + block_offset) * row;
+    HIP_TRY(hipMemcpyAsync(pool->k_layer(layer) + at, k_row, row * sizeof(float), hipMemcpyHostToDevice, pool->stream));
+    HIP_TRY(hipMemcpyAsync(pool->v_layer(layer) + at, v_row, row * sizeof(float), hipMemcpyHostToDevice, pool->stream));
+    // the caller may reuse k_row/v_row as soon as we return (the reference's memcpy is synchronous too)
+    HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *k_rows, const float *v_rows,
+                          const int *block_tables, int max_blocks, const int *positions, int ptr_kind)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_append_batch");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_seqs < 0 || max_blocks <= 0 || (num_seqs > 0 && (!k_rows || !v_rows || !block_tables || !positions)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append_batch: bad arguments");
+    if (num_seqs == 0)
+        return NVK_OK;
+    DeviceScope  scope(pool->device);
+    const int    row = pool->row_len();
+    const float *dk = k_rows, *dv = v_rows;
+    const int   *dt = block_tables, *dp = positions;
+    if (ptr_kind == NVK_PTR_HOST) {
+        // validate where the reference would have undefined behaviour or throw
+        for (int s = 0; s < num_seqs; s++) {
+            const int pos = positions[s];
+            if (pos < 0 || pos / pool->block_size >= max_blocks)
+                return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append_batch: position %d of sequence %d outside its table",
+                                 pos, s);
+            const int pb = block_tables[(size_t)s * max_blocks + pos / pool->block_size];
+            if (pb < 0 || pb >= pool->num_blocks)
+                return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_append_batch: block %d of sequence %d outside [0,%d)", pb, s,
+                                 pool->num_blocks);
+        }
+        const size_t rows_b = (size_t)num_seqs * row * sizeof(float);
+        const size_t tab_b  = (size_t)num_seqs * max_blocks * sizeof(int);
+        const size_t pos_b  = (size_t)num_seqs * sizeof(int);
+        const size_t a1     = (rows_b + 255) / 256 * 256; // 256-B aligned sections
+        const size_t a2     = (tab_b + 255) / 256 * 256;
+        rc              = ensure_stage(pool, 2 * a1 + a2 + pos_b + 256);
+        if (rc != NVK_OK)
+            return rc;
+        char *base = pool->stage;
+        HIP_TRY(hipMemcpyAsync(base, k_rows, rows_b, hipMemcpyHostToDevice, pool->stream));
+        HIP_TRY(hipMemcpyAsync(base + a1, v_rows, rows_b, hipMemcpyHostToDevice, pool->stream));
+        HIP_TRY(hipMemcpyAsync(base + 2 * a1, block_tables, tab_b, hipMemcpyHostToDevice, pool->stream));
+        HIP_TRY(hipMemcpyAsync(base + 2 * a1 + a2, positions, pos_b, hipMemcpyHostToDevice, pool->stream));
+        dk = (const float *)base;
+        dv = (const float *)(base + a1);
+        dt = (const int *)(base + 2 * a1);
+        dp = (const int *)(base + 2 * a1 + a2);
+    }
+    else if (ptr_kind != NVK_PTR_DEVICE) {
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append_batch: ptr_kind %d", ptr_kind);
+    }
+    hipLaunchKernelGGL(nvk::nvk_append_kernel, dim3((unsigned)num_seqs), dim3(256), 0, pool->stream, pool->k_layer(layer),
+                       pool->v_layer(layer), dk, dv, dt, max_blocks, dp, pool->num_blocks, pool->block_size,
+                       pool->bs_shift, row);
+    HIP_TRY(hipGetLastError());
+    if (ptr_kind == NVK_PTR_HOST)
+        HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const float *k_block, const float *v_block)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_upload_block");
+    if (rc != NVK_OK)
+        return rc;
+    if (physical_block < 0 || physical_block >= pool->num_blocks)
+        return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_upload_block: block %d outside [0,%d)", physical_block,
+                         pool->num_blocks);
+    DeviceScope  scope(pool->device);
+    const size_t blk = (size_t)pool->block_size * pool->row_len();
+    if (k_block)
+        HIP_TRY(hipMemcpyAsync(pool->k_layer(layer) + physical_block * blk, k_block, blk * sizeof(float),
+                               hipMemcpyHostToDevice, pool->stream));
+    if (v_block)
+        HIP_TRY(hipMemcpyAsync(pool->v_layer(layer) + physical_block * blk, v_block, blk * sizeof(float),
+                               hipMemcpyHostToDevice, pool->stream));
+    HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_download_block(nvk_pool *pool, int layer, int physical_block, float *k_block, float *v_block)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_download_block");
+    if (rc != NVK_OK)
+        return rc;
+    if (physical_block < 0 || physical_block >= pool->num_blocks)
+        return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_download_block: block %d outside [0,%d)", physical_block,
+                         pool->num_blocks);
+    DeviceScope  scope(pool->device);
+    const size_t blk = (size_t)pool->block_size * pool->row_len();
+    if (k_block)
+        HIP_TRY(hipMemcpyAsync(k_block, pool->k_layer(layer) + physical_block * blk, blk * sizeof(float),
+                               hipMemcpyDeviceToHost, pool->stream));
+    if (v_block)
+        HIP_TRY(hipMemcpyAsync(v_block, pool->v_layer(layer) + physical_block * blk, blk * sizeof(float),
+                               hipMemcpyDeviceToHost, pool->stream));
+    HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_gather(nvk_pool *pool, int layer, const int *block_table, int num_tokens, int kv_head, float *k_out,
+                    float *v_out)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_gather");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_tokens < 0 || kv_head < 0 || kv_head >= pool->n_kv_heads || (num_tokens > 0 && (!block_table || !k_out || !v_out)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_gather: bad arguments");
+    if (num_tokens == 0)
+        return NVK_OK;
+    const int nblk = (num_tokens + pool->block_size - 1) / pool->block_size;
+    for (int i = 0; i < nblk; i++)
+        if (block_table[i] < 0 || block_table[i] >= pool->num_blocks)
+            return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_gather: table[%d]=%d outside [0,%d)", i, block_table[i],
+                             pool->num_blocks);
+    DeviceScope  scope(pool->device);
+    const size_t out_b = (size_t)num_tokens * pool->head_dim * sizeof(float);
+    const size_t out_a = (out_b + 255) / 256 * 256;
+    const size_t tab_b = (size_t)nblk * sizeof(int);
+    rc                 = ensure_stage(pool, 2 * out_a + tab_b);
+    if (rc != NVK_OK)
+        return rc;
+    float *dk = (float *)pool->stage;
+    float *dv = (float *)(pool->stage + out_a);
+    int   *dt = (int *)(pool->stage + 2 * out_a);
+    HIP_TRY(hipMemcpyAsync(dt, block_table, tab_b, hipMemcpyHostToDevice, pool->stream));
+    hipLaunchKernelGGL(nvk::nvk_gather_kernel, dim3((unsigned)num_tokens), dim3(64), 0, pool->stream, pool->k_layer(layer),
+                       pool->v_layer(layer), dt, num_tokens, kv_head, pool->num_blocks, pool->block_size, pool->bs_shift,
+                       pool->n_kv_heads, pool->head_dim, dk, dv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(k_out, dk, out_b, hipMemcpyDeviceToHost, pool->stream));
+    HIP_TRY(hipMemcpyAsync(v_out, dv, out_b, hipMemcpyDeviceToHost, pool->stream));
+    HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_fill_uniform(nvk_pool *pool, int layer, uint64_t seed_k, uint64_t seed_v)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_fill_uniform");
+    if (rc != NVK_OK)
+        return rc;
+    DeviceScope scope(pool->device);
+    const dim3  grid((unsigned)(pool->num_cus * 8)), block(256);
+    hipLaunchKernelGGL(nvk::nvk_fill_kernel, grid, block, 0, pool->stream, pool->k_layer(layer), seed_k,
+                       (uint64_t)pool->layer_floats);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(nvk::nvk_fill_kernel, grid, block, 0, pool->stream, pool->v_layer(layer), seed_v,
+                       (uint64_t)pool->layer_floats);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int chunk_tokens)
+{
+    if (!pool || num_seqs < 0 || max_ctx < 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_reserve_workspace: bad arguments");
+    DeviceScope scope(pool->device);
+    LaunchPlan  plan;
+    int rc = make_plan(pool, num_seqs, n_heads, max_ctx, chunk_tokens > 0 ? NVK_DECODE_SPLIT_K : NVK_DECODE_AUTO,
+                       chunk_tokens, &plan);
+    if (rc != NVK_OK)
+        return rc;
+    return ensure_workspace(pool, (size_t)num_seqs * plan.max_chunks * n_heads * pool->head_dim,
+                            (size_t)num_seqs * plan.max_chunks * n_heads * 2);
+}
+
+int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                      const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx, float *out_dev,
+                      int flags, int chunk_tokens, void *stream)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_decode_device");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_seqs < 0 || max_blocks <= 0 || max_ctx < 0
+        || (num_seqs > 0 && (!q_dev || !block_tables_dev || !ctx_lens_dev || !out_dev)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: bad arguments");
+    if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: flags %d", flags);
+    DeviceScope scope(pool->device);
+    return enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
+                          out_dev, flags, chunk_tokens, stream ? (hipStream_t)stream : pool->stream, nullptr, nullptr);
+}
+
+int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q, const int *block_tables,
+               int max_blocks, const int *ctx_lens, float *out, int flags, int chunk_tokens)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_decode");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_seqs < 0 || max_blocks <= 0 || (num_seqs > 0 && (!q || !block_tables || !ctx_lens || !out)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode: bad arguments");
+    if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode: flags %d", flags);
+    if (num_seqs == 0)
+        return NVK_OK;
+
+    // Host-side validation of everything the kernel will dereference through.
+    int max_ctx = 0;
+    for (int s = 0; s < num_seqs; s++) {
+        const int ctx = ctx_lens[s];
+        if (ctx < 0)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode: ctx_lens[%d]=%d is negative", s, ctx);
+        const int nblk = (ctx + pool->block_size - 1) / pool->block_size;
+        if (nblk > max_blocks)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode: sequence %d needs %d blocks, table rows hold %d", s, nblk,
+                             max_blocks);
+        for (int i = 0; i < nblk; i++) {
+            const int pb = block_tables[(size_t)s * max_blocks + i];
+            if (pb < 0 || pb >= pool->num_blocks)
+                return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_decode: block_tables[%d][%d]=%d outside [0,%d)", s, i, pb,
+                                 pool->num_blocks);
+        }
+        max_ctx = std::max(max_ctx, ctx);
+    }
+
+    DeviceScope  scope(pool->device);
+    const size_t q_b   = (size_t)num_seqs * n_heads * pool->head_dim * sizeof(float);
+    const size_t q_a   = (q_b + 255) / 256 * 256;
+    const size_t tab_b = (size_t)num_seqs * max_blocks * sizeof(int);
+    const size_t tab_a = (tab_b + 255) / 256 * 256;
+    const size_t ctx_b = (size_t)num_seqs * sizeof(int);
+    const size_t ctx_a = (ctx_b + 255) / 256 * 256;
+    rc                 = ensure_stage(pool, 2 * q_a + tab_a + ctx_a);
+    if (rc != NVK_OK)
+        return rc;
+    float *dq   = (float *)pool->stage;
+    float *dout = (float *)(pool->stage + q_a);
+    int   *dtab = (int *)(pool->stage + 2 * q_a);
+    int   *dctx = (int *)(pool->stage + 2 * q_a + tab_a);
+    HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, pool->stream));
+    HIP_TRY(hipMemcpyAsync(dtab, block_tables, tab_b, hipMemcpyHostToDevice, pool->stream));
+    HIP_TRY(hipMemcpyAsync(dctx, ctx_lens, ctx_b, hipMemcpyHostToDevice, pool->stream));
+    rc = enqueue_decode(pool, layer, num_seqs, n_heads, dq, dtab, max_blocks, dctx, max_ctx, dout, flags, chunk_tokens,
+                        pool->stream, nullptr, nullptr);
+    if (rc != NVK_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, q_b, hipMemcpyDeviceToHost, pool->stream));
+    HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                     const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx, float *out_dev,
+                     int flags, int chunk_tokens, int warmup, int iters, float *total_ms, float *attn_ms)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_decode_bench");
+    if (rc != NVK_OK)
+        return rc;
+    if (iters < 0 || warmup < 0 || num_seqs <= 0 || iters > 100000)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_bench: need 0 <= iters <= 100000, warmup >= 0, num_seqs > 0");
+    DeviceScope scope(pool->device);
+    hipStream_t st = pool->stream;
+    for (int i = 0; i < warmup; i++) {
+        rc = enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
+                            out_dev, flags, chunk_tokens, st, nullptr, nullptr);
+        if (rc != NVK_OK)
+            return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (total_ms)
+        *total_ms = 0.f;
+    if (attn_ms)
+        *attn_ms = 0.f;
+    if (iters == 0)
+        return NVK_OK;
+
+    // One timed region: ev_a .. ev_b brackets all `iters` layer-calls; inside it, when
+    // attn_ms is wanted, each attention-kernel launch is bracketed by its own event pair.
+    std::vector<hipEvent_t> ev(attn_ms ? (size_t)2 * iters : 0, nullptr);
+    hipError_t              e = hipSuccess;
+    for (auto &x : ev)
+        if (e == hipSuccess)
+            e = hipEventCreate(&x);
+    if (e == hipSuccess)
+        e = hipEventRecord(pool->ev_a, st);
+    for (int i = 0; i < iters && e == hipSuccess && rc == NVK_OK; i++)
+        rc = enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
+                            out_dev, flags, chunk_tokens, st, attn_ms ? ev[2 * i] : nullptr,
+                            attn_ms ? ev[2 * i + 1] : nullptr);
+    if (e == hipSuccess)
+        e = hipEventRecord(pool->ev_b, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    float whole = 0.f;
+    if (e == hipSuccess && rc == NVK_OK)
+        e = hipEventElapsedTime(&whole, pool->ev_a, pool->ev_b);
+    double kernels = 0.0;
+    if (attn_ms && e == hipSuccess && rc == NVK_OK)
+        for (int i = 0; i < iters && e == hipSuccess; i++) {
+            float one = 0.f;
+            e         = hipEventElapsedTime(&one, ev[2 * i], ev[2 * i + 1]);
+            kernels += one;
+        }
+    for (auto &x : ev)
+        if (x)
+            (void)hipEventDestroy(x);
+    if (rc != NVK_OK)
+        return rc;
+    if (e != hipSuccess)
+        return nvk::fail(NVK_ERR_HIP, "nvk_decode_bench: %s", hipGetErrorString(e));
+    if (total_ms)
+        *total_ms = whole / iters;
+    if (attn_ms)
+        *attn_ms = (float)(kernels / iters);
+    return NVK_OK;
+}
+
+int nvk_bind_pool(nvk_pool *pool, int layer)
+{
+    if (!pool) {
+        t_bound_pool = nullptr;
+        return NVK_OK;
+    }
+    int rc = check_pool_layer(pool, layer, "nvk_bind_pool");
+    if (rc != NVK_OK)
+        return rc;
+    t_bound_pool  = pool;
+    t_bound_layer = layer;
+    return NVK_OK;
+}
+
+int nvk_paged_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
+                        const int *block_table, float *att_scores, int num_tokens, int block_size, int head_dim,
+                        int n_heads, int n_kv_heads)
+{
+    (void)att_scores; // the reference's [n_heads, num_tokens] scratch has no device counterpart
+    if (!out || !q || num_tokens < 0 || block_size <= 0 || head_dim <= 0 || n_heads <= 0 || n_kv_heads <= 0
+        || (num_tokens > 0 && !block_table))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_paged_attention: bad arguments");
+    const int nblk = std::max(1, (num_tokens + block_size - 1) / block_size);
+
+    if (t_bound_pool) {
+        nvk_pool *pool = t_bound_pool;
+        if (pool->block_size != block_size || pool->head_dim != head_dim || pool->n_kv_heads != n_kv_heads)
+            return nvk::fail(NVK_ERR_INVALID_ARG,
+                             "nvk_paged_attention: bound pool is (bs=%d, hd=%d, kv=%d), call says (%d, %d, %d)",
+                             pool->block_size, pool->head_dim, pool->n_kv_heads, block_size, head_dim, n_kv_heads);
+        if (num_tokens == 0) {
+            std::memset(out, 0, (size_t)n_heads * head_dim * sizeof(float)); // attention.hpp:98, nothing to launch
+            return NVK_OK;
+        }
+        return nvk_decode(pool, t_bound_layer, 1, n_heads, q, block_table, nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
+    }
+
+    // Unbound: key_cache/value_cache are host slabs of one layer.  Stage the blocks
+    // this sequence names into a one-layer scratch pool and run the same kernels.
+    if (!key_cache || !value_cache)
+        return nvk::fail(NVK_ERR_UNBOUND, "nvk_paged_attention: no pool bound and no host cache given");
+    if (num_tokens == 0) {
+        std::memset(out, 0, (size_t)n_heads * head_dim * sizeof(float));
+        return NVK_OK;
+    }
+    nvk_pool *sp = t_scratch_pool;
+    if (!sp || sp->block_size != block_size || sp->head_dim != head_dim || sp->n_kv_heads != n_kv_heads
+        || sp->num_blocks < nblk) {
+        if (sp)
+            nvk_pool_destroy(sp);
+        t_scratch_pool = nullptr;
+        int dev        = 0;
+        if (hipGetDevice(&dev) != hipSuccess)
+            dev = 0;
+        int rc = nvk_pool_create(1, std::max(nblk, 64), block_size, n_kv_heads, head_dim, dev, &sp);
+        if (rc != NVK_OK)
+            return rc;
+        t_scratch_pool = sp;
+    }
+    const size_t     blk = (size_t)block_size * n_kv_heads * head_dim;
+    std::vector<int> local((size_t)nblk);
+    for (int i = 0; i < nblk; i++) {
+        if (block_table[i] < 0)
+            return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_paged_attention: block_table[%d]=%d is negative", i, block_table[i]);
+        int rc = nvk_pool_upload_block(sp, 0, i, key_cache + (size_t)block_table[i] * blk,
+                                       value_cache + (size_t)block_table[i] * blk);
+        if (rc != NVK_OK)
+            return rc;
+        local[(size_t)i] = i;
+    }
+    return nvk_decode(sp, 0, 1, n_heads, q, local.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
+}
+
+} // extern "C"

@@ -1,0 +1,260 @@
+"""Definitions shared by oracle/make_golden.py (which records the reference's
+answers) and the tests (which replay them): the list of cases, how their inputs
+are derived from seeds, and the BlockManager op scripts.  Data and seeds only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from typing import Dict, List
+
+import numpy as np
+
+from nano_vllm_amd.workloads import shuffled_permutation, splitmix64, uniform
+
+# ------------------------------------------------------------------ F2 cases
+# (n_heads, n_kv_heads, head_dim, block_size, num_tokens[, q_gain])
+_RAW = [
+    # G-tiny geometry, the default stories15M shape
+    (6, 6, 48, 16, 1), (6, 6, 48, 16, 15), (6, 6, 48, 16, 16), (6, 6, 48, 16, 17), (6, 6, 48, 16, 37),
+    (6, 6, 48, 16, 256),
+    # G-llama
+    (32, 8, 128, 16, 1), (32, 8, 128, 16, 16), (32, 8, 128, 16, 2048),
+    # G-mha
+    (32, 32, 128, 16, 513),
+    (8, 2, 64, 32, 100),
+    # beyond the survey's list: other block sizes (incl. non power of two), head dims, group sizes, peaked softmax
+    (8, 4, 128, 8, 77), (4, 4, 32, 4, 9), (12, 3, 64, 12, 50), (4, 2, 256, 16, 40), (8, 8, 80, 16, 33),
+    (16, 2, 64, 16, 70), (6, 2, 16, 16, 45), (32, 8, 128, 16, 300, 6.0), (6, 6, 48, 16, 200, 8.0),
+    (32, 8, 128, 16, 0), (5, 5, 20, 16, 23), (16, 1, 128, 16, 129),
+]
+
+ATTENTION_CASES: List[Dict] = []
+for _i, _c in enumerate(_RAW):
+    H, KV, hd, bs, T = _c[:5]
+    ATTENTION_CASES.append({
+        "name": f"h{H}_kv{KV}_d{hd}_bs{bs}_t{T}" + (f"_g{int(_c[5])}" if len(_c) > 5 else ""),
+        "index": _i, "n_heads": H, "n_kv_heads": KV, "head_dim": hd, "block_size": bs, "num_tokens": T,
+        "q_gain": float(_c[5]) if len(_c) > 5 else 1.0,
+    })
+
+
+def attention_case_inputs(case):
+    """q [H, hd], k_pool/v_pool [num_blocks, bs, KV, hd], table [ceil(T/bs)] for a case.
+
+    The pool has a few more blocks than the sequence needs and the table is a
+    seeded shuffle of it, so logical order != physical order; every pool element
+    (used or not) holds a distinct seeded value."""
+    i, H, KV, hd, bs, T = case["index"], case["n_heads"], case["n_kv_heads"], case["head_dim"], \
+        case["block_size"], case["num_tokens"]
+    need = (T + bs - 1) // bs
+    num_blocks = need + 3
+    perm = shuffled_permutation(num_blocks, 7000 + i)
+    table = perm[:max(need, 1)].astype(np.int32)
+    n = num_blocks * bs * KV * hd
+    k_pool = uniform(1000 + i, 0, n).reshape(num_blocks, bs, KV, hd)
+    v_pool = uniform(2000 + i, 0, n).reshape(num_blocks, bs, KV, hd)
+    q = (uniform(3000 + i, 0, H * hd) * np.float32(case["q_gain"])).reshape(H, hd)
+    return q, k_pool, v_pool, table
+
+
+# ------------------------------------------------------------ F1 BM scripts
+def bm_trace_script():
+    scripts = []
+    ops = [["alloc"]] * 9 + [["num_free"], ["util"], ["free", 3], ["free", 3], ["free", 5], ["is_free", 3],
+                              ["is_free", 4], ["is_free", -1], ["is_free", 8], ["alloc"], ["alloc"], ["alloc"],
+                              ["free", -1], ["free", 8], ["free", 0], ["free", 7], ["alloc"], ["alloc"], ["util"],
+                              ["num_free"]]
+    scripts.append({"name": "fill_exhaust_reuse", "num_blocks": 8, "block_size": 16, "ops": ops})
+
+    ops = [["alloc_seq", 9], ["num_free"], ["alloc_seq", 30], ["num_free"], ["alloc_seq", 0], ["free_seq", [1]],
+           ["alloc_seq", 28], ["num_free"], ["alloc_seq", 1], ["free_seq", [0, 2]], ["alloc_seq", 5],
+           ["free_seq", [3, 99, 4]], ["num_free"], ["is_free", 3], ["is_free", 4], ["free_seq", []], ["alloc_seq", 4],
+           ["alloc_seq", 4], ["alloc_seq", 4], ["util"]]
+    scripts.append({"name": "sequences", "num_blocks": 10, "block_size": 4, "ops": ops})
+
+    ops = [["req_alloc", 7, 40], ["req_alloc", 9, 17], ["active"], ["req_count", 7], ["req_blocks", 9],
+           ["req_alloc_block", 7], ["req_alloc_block", 11], ["req_blocks", 7], ["req_alloc", 12, 1000],
+           ["active"], ["req_count", 12], ["req_free", 9], ["active"], ["num_free"], ["req_alloc", 9, 16],
+           ["req_blocks", 9], ["req_free", 404], ["req_alloc", 5, 0], ["active"], ["req_count", 5],
+           ["req_free", 7], ["req_free", 11], ["req_free", 9], ["num_free"], ["active"], ["alloc"],
+           ["req_alloc_block", 1], ["req_blocks", 1]]
+    scripts.append({"name": "per_request", "num_blocks": 12, "block_size": 16, "ops": ops})
+
+    # a long pseudo-random mix on an odd-sized pool (crosses a 64-bit word boundary of the bitmap)
+    nb = 131
+    draws = splitmix64(555, np.arange(1200, dtype=np.uint64))
+    ops = []
+    for d in draws.tolist():
+        r = d % 100
+        arg = (d >> 8) % (nb + 6) - 3
+        if r < 45:
+            ops.append(["alloc"])
+        elif r < 75:
+            ops.append(["free", int(arg)])
+        elif r < 85:
+            ops.append(["alloc_seq", int((d >> 20) % 200)])
+        elif r < 92:
+            ops.append(["is_free", int(arg)])
+        elif r < 96:
+            ops.append(["num_free"])
+        else:
+            ops.append(["req_alloc", int((d >> 30) % 5), int((d >> 20) % 90)] if r < 98
+                       else ["req_free", int((d >> 30) % 5)])
+    scripts.append({"name": "random_mix_131", "num_blocks": nb, "block_size": 8, "ops": ops})
+    return scripts
+
+
+class BmCLib:
+    """Adapter: a C library exposing <prefix>bm_* (the oracle or the reference shim)."""
+
+    def __init__(self, lib, prefix, num_blocks, block_size):
+        self.lib, self.prefix = lib, prefix
+        self.bm = self._f("create")(num_blocks, block_size)
+        self.cap = max(num_blocks, 1)
+        self.buf = (C.c_int * self.cap)()
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + "bm_" + name)
+
+    def close(self):
+        self._f("destroy")(self.bm)
+
+    def do(self, op):
+        kind = op[0]
+        if kind == "alloc":
+            return int(self._f("allocate_block")(self.bm))
+        if kind == "free":
+            return 0 if self._f("free_block")(self.bm, op[1]) == 0 else "throw"
+        if kind == "alloc_seq":
+            n = int(self._f("allocate_sequence")(self.bm, op[1], self.buf, self.cap))
+            return list(self.buf[:n]) if n >= 0 else "throw"
+        if kind == "free_seq":
+            arr = (C.c_int * max(len(op[1]), 1))(*op[1])
+            return 0 if self._f("free_sequence")(self.bm, arr, len(op[1])) == 0 else "throw"
+        if kind == "req_alloc":
+            n = int(self._f("allocate_for_request")(self.bm, op[1], op[2], self.buf, self.cap))
+            return list(self.buf[:n])
+        if kind == "req_alloc_block":
+            return int(self._f("allocate_block_for_request")(self.bm, op[1]))
+        if kind == "req_free":
+            self._f("free_request")(self.bm, op[1])
+            return None
+        if kind == "req_blocks":
+            n = int(self._f("get_request_blocks")(self.bm, op[1], self.buf, self.cap))
+            return list(self.buf[:n])
+        if kind == "req_count":
+            return int(self._f("get_request_block_count")(self.bm, op[1]))
+        if kind == "active":
+            return int(self._f("num_active_requests")(self.bm))
+        if kind == "num_free":
+            return int(self._f("num_free")(self.bm))
+        if kind == "is_free":
+            return int(self._f("is_free")(self.bm, op[1]))
+        if kind == "util":
+            return float(self._f("utilization")(self.bm))
+        raise ValueError(kind)
+
+
+class BmProduct:
+    """Adapter: nano_vllm_amd.BlockManager (the C ABI through the host mirror)."""
+
+    def __init__(self, num_blocks, block_size):
+        from nano_vllm_amd import BlockManager
+        self.bm = BlockManager(num_blocks, block_size)
+
+    def close(self):
+        self.bm = None
+
+    def do(self, op):
+        kind, bm = op[0], self.bm
+        try:
+            if kind == "alloc":
+                return bm.allocate_block()
+            if kind == "free":
+                bm.free_block(op[1])
+                return 0
+            if kind == "alloc_seq":
+                return bm.allocate_sequence(op[1])
+            if kind == "free_seq":
+                bm.free_sequence(op[1])
+                return 0
+        except RuntimeError:
+            return "throw"
+        if kind == "req_alloc":
+            return bm.allocate_for_request(op[1], op[2])
+        if kind == "req_alloc_block":
+            return bm.allocate_block_for_request(op[1])
+        if kind == "req_free":
+            bm.free_request(op[1])
+            return None
+        if kind == "req_blocks":
+            return bm.get_request_blocks(op[1])
+        if kind == "req_count":
+            return bm.get_request_block_count(op[1])
+        if kind == "active":
+            return bm.get_num_active_requests()
+        if kind == "num_free":
+            return bm.get_num_free_blocks()
+        if kind == "is_free":
+            return int(bm.is_free(op[1]))
+        if kind == "util":
+            return bm.get_utilization()
+        raise ValueError(kind)
+
+
+def replay(adapter, ops):
+    out = [adapter.do(op) for op in ops]
+    adapter.close()
+    return out
+
+
+# --------------------------------------------------------------- F4 models
+def _tokens(seed, n, vocab):
+    return [int(x) for x in (splitmix64(seed, np.arange(n, dtype=np.uint64)) % np.uint64(vocab)).tolist()]
+
+
+TINY_MODELS = [
+    # a GQA miniature: 6 q-heads over 2 kv-heads (kv_mul 3), head_dim 16, 3 layers
+    dict(name="mini_gqa", dim=96, hidden_dim=256, n_layers=3, n_heads=6, n_kv_heads=2, vocab_size=97,
+         max_seq_len=96, block_size=16, num_blocks=64, weight_seed=11, weight_gain=0.35, shared=True,
+         forced_tokens=_tokens(21, 50, 97), prompt_tokens=[1] + _tokens(22, 5, 97), gen_steps=50),
+    # the default checkpoint's geometry (stories15M: 6 layers, 6/6 heads, head_dim 48) with a small vocabulary;
+    # block_size/num_blocks are the reference's compile-time defaults (model.hpp:35-36)
+    dict(name="g_tiny", dim=288, hidden_dim=768, n_layers=6, n_heads=6, n_kv_heads=6, vocab_size=512,
+         max_seq_len=256, block_size=16, num_blocks=256, weight_seed=12, weight_gain=0.30, shared=False,
+         forced_tokens=_tokens(23, 40, 512), prompt_tokens=[1] + _tokens(24, 7, 512), gen_steps=50),
+]
+
+
+def checkpoint_tensors(spec):
+    """Weights of the synthetic checkpoint, in llama2.c file order (reference model.hpp:322-347)."""
+    D, Hd, L = spec["dim"], spec["hidden_dim"], spec["n_layers"]
+    hd = D // spec["n_heads"]
+    QD, KD, V = spec["n_heads"] * hd, spec["n_kv_heads"] * hd, spec["vocab_size"]
+    sizes = [("tok_emb", V * D), ("rms_att", L * D), ("wq", L * D * QD), ("wk", L * D * KD), ("wv", L * D * KD),
+             ("wo", L * QD * D), ("rms_ffn", L * D), ("w_gate", L * D * Hd), ("w_down", L * Hd * D),
+             ("w_up", L * D * Hd), ("rms_final", D)]
+    if not spec["shared"]:
+        sizes.append(("lm_head", V * D))
+    out, at = [], 0
+    for name, n in sizes:
+        w = uniform(spec["weight_seed"], at, n)
+        at += n
+        if name.startswith("rms"):
+            w = (np.float32(1.0) + np.float32(0.1) * w).astype(np.float32)
+        elif name in ("tok_emb", "lm_head"):
+            w = w.astype(np.float32)
+        else:
+            w = (w * np.float32(spec["weight_gain"])).astype(np.float32)
+        out.append((name, w))
+    return out
+
+
+def write_checkpoint(path, spec):
+    """llama2.c format: 7 int32 header (dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, max_seq_len)."""
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("7i", spec["dim"], spec["hidden_dim"], spec["n_layers"], spec["n_heads"],
+                             spec["n_kv_heads"], spec["vocab_size"], spec["max_seq_len"]))
+        for _, w in checkpoint_tensors(spec):
+            fh.write(w.tobytes())

@@ -1,0 +1,289 @@
+"""Parity of the HIP path, through the C ABI, against the golden vectors and the CPU checker.
+
+Tolerance (BASELINE.json north_star): fp32 outputs within 1e-4 max-abs / 1e-5
+relative of the reference, i.e. |got - want| <= 1e-4 + 1e-5 * |want| elementwise.
+The KV gather and the block allocator are integer/byte work and must be bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import nano_vllm_amd as nv
+import oracle_lib as ol
+from golden_defs import ATTENTION_CASES, attention_case_inputs
+from nano_vllm_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-4, 1e-5
+
+
+def assert_close(got, want, what=""):
+    got = np.asarray(got, np.float32)
+    want = np.asarray(want, np.float32)
+    assert got.shape == want.shape, what
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern differs"
+    ok = np.abs(got - want) <= ATOL + RTOL * np.abs(want)
+    ok |= np.isnan(want)
+    assert ok.all(), f"{what}: max abs err {np.nanmax(np.abs(got - want)):.3e}"
+
+
+def pool_from_host(k_pool, v_pool, n_layers=1, layer=0):
+    nb, bs, kv, hd = k_pool.shape
+    pool = nv.PagedKVPool(n_layers, nb, bs, kv, hd)
+    for b in range(nb):
+        pool.upload_block(layer, b, k_pool[b], v_pool[b])
+    return pool
+
+
+@pytest.mark.parametrize("case", ATTENTION_CASES, ids=[c["name"] for c in ATTENTION_CASES])
+def test_golden_cases_all_modes(case, golden_dir):
+    """Every golden case through decode(): auto, single-pass and two split-K chunkings."""
+    gold = np.load(os.path.join(golden_dir, "attention_cases.npz"))[case["name"] + "/out"]
+    q, k_pool, v_pool, table = attention_case_inputs(case)
+    T = case["num_tokens"]
+    with pool_from_host(k_pool, v_pool) as pool:
+        tabs = table[None, :]
+        ctx = np.array([T], np.int32)
+        for flags, chunk in ((nv.AUTO, 0), (nv.SINGLE_PASS, 0), (nv.SPLIT_K, 8), (nv.SPLIT_K, 64)):
+            out = nv.decode(pool, 0, q[None], tabs, ctx, flags, chunk)[0]
+            assert_close(out, gold, f"{case['name']} flags={flags} chunk={chunk}")
+
+
+@pytest.mark.parametrize("case", ATTENTION_CASES[:12], ids=[c["name"] for c in ATTENTION_CASES[:12]])
+def test_drop_in_signature(case, golden_dir):
+    """nvk_paged_attention with the reference's eleven arguments: host slabs (unbound) and bound pool."""
+    gold = np.load(os.path.join(golden_dir, "attention_cases.npz"))[case["name"] + "/out"]
+    q, k_pool, v_pool, table = attention_case_inputs(case)
+    H, KV, hd, bs, T = (case[k] for k in ("n_heads", "n_kv_heads", "head_dim", "block_size", "num_tokens"))
+    scratch = np.empty(H * max(T, 1), np.float32)
+
+    nv.bind_pool(None)
+    out = np.full((H, hd), np.nan, np.float32)
+    nv.paged_attention(out, q, k_pool, v_pool, table, scratch, T, bs, hd, H, KV)
+    assert_close(out, gold, "unbound")
+
+    with pool_from_host(k_pool, v_pool, n_layers=3, layer=2) as pool:
+        nv.bind_pool(pool, 2)
+        try:
+            out = np.full((H, hd), np.nan, np.float32)
+            nv.paged_attention(out, q, None, None, table, None, T, bs, hd, H, KV)
+            assert_close(out, gold, "bound")
+            with pytest.raises(nv.NvkError):  # geometry mismatch is an error, not UB
+                nv.paged_attention(out, q, None, None, table, None, T, bs + 1, hd, H, KV)
+        finally:
+            nv.bind_pool(None)
+
+
+def test_gather_is_bit_exact():
+    """Block-table indexing and KV gather: identical bytes to the closed form of attention.hpp:109-115."""
+    case = next(c for c in ATTENTION_CASES if c["name"].startswith("h12_kv3_d64_bs12"))  # non power-of-two block
+    for case in (case, ATTENTION_CASES[4], ATTENTION_CASES[8]):
+        q, k_pool, v_pool, table = attention_case_inputs(case)
+        T, bs = case["num_tokens"], case["block_size"]
+        with pool_from_host(k_pool, v_pool) as pool:
+            for kvh in range(case["n_kv_heads"]):
+                k, v = pool.gather(0, table, T, kvh)
+                want_k = np.stack([k_pool[table[t // bs], t % bs, kvh] for t in range(T)])
+                want_v = np.stack([v_pool[table[t // bs], t % bs, kvh] for t in range(T)])
+                assert np.array_equal(k.view(np.uint32), want_k.view(np.uint32))
+                assert np.array_equal(v.view(np.uint32), want_v.view(np.uint32))
+
+
+def test_device_fill_matches_generator():
+    g = wl.Geometry(8, 2, 64, 16)
+    with nv.PagedKVPool(2, 37, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(1, 11, 22)
+        for pb in (0, 5, 36):
+            k, v = pool.download_block(1, pb)
+            assert np.array_equal(k.reshape(-1), wl.uniform_block(11, pb, g.block_floats))
+            assert np.array_equal(v.reshape(-1), wl.uniform_block(22, pb, g.block_floats))
+            assert np.array_equal(k.reshape(-1), ol.oracle_fill_uniform(11, pb * g.block_floats, g.block_floats))
+        k0, _ = pool.download_block(0, 0)
+        assert not k0.any()  # other layers stay zero-initialised (model.hpp:267-268)
+
+
+def test_append_then_attend_like_the_model_loop():
+    """KV append + attention in the order of LlamaModel::forward (model.hpp:178-221): token pos attends to itself."""
+    H, KV, hd, bs, L = 8, 2, 64, 16, 2
+    nb = 12
+    rng = np.random.default_rng(5)
+    bm = nv.BlockManager(nb, bs)
+    host_k = np.zeros((L, nb, bs, KV, hd), np.float32)
+    host_v = np.zeros_like(host_k)
+    tables = [[] for _ in range(L)]
+    with nv.PagedKVPool(L, nb, bs, KV, hd) as pool:
+        for pos in range(40):
+            for layer in range(L):
+                if pos % bs == 0:
+                    tables[layer].append(bm.allocate_block())
+                k = rng.standard_normal((KV, hd), dtype=np.float32)
+                v = rng.standard_normal((KV, hd), dtype=np.float32)
+                q = rng.standard_normal((H, hd), dtype=np.float32)
+                pb, off = tables[layer][pos // bs], pos % bs
+                pool.append(layer, pb, off, k, v)
+                host_k[layer, pb, off], host_v[layer, pb, off] = k, v
+                tab = np.asarray(tables[layer], np.int32)
+                got = nv.decode(pool, layer, q[None], tab[None], np.array([pos + 1], np.int32))[0]
+                want = ol.oracle_paged_attention(q, host_k[layer], host_v[layer], tab, pos + 1, bs, hd, H, KV)
+                assert_close(got, want, f"pos {pos} layer {layer}")
+        assert tables[0] == [0, 2, 4] and tables[1] == [1, 3, 5]  # shared free list interleaves layers
+
+
+def test_append_batch_matches_per_row_append():
+    H, KV, hd, bs = 4, 4, 32, 8
+    n, nb = 9, 40
+    rng = np.random.default_rng(6)
+    tabs = rng.permutation(nb)[: n * 4].reshape(n, 4).astype(np.int32)
+    pos = rng.integers(0, 4 * bs, n).astype(np.int32)
+    k = rng.standard_normal((n, KV * hd), dtype=np.float32)
+    v = rng.standard_normal((n, KV * hd), dtype=np.float32)
+    with nv.PagedKVPool(1, nb, bs, KV, hd) as a, nv.PagedKVPool(1, nb, bs, KV, hd) as b:
+        a.append_batch(0, k, v, tabs, pos)
+        for s in range(n):
+            b.append(0, int(tabs[s, pos[s] // bs]), int(pos[s] % bs), k[s], v[s])
+        for pb in range(nb):
+            ka, va = a.download_block(0, pb)
+            kb, vb = b.download_block(0, pb)
+            assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+        bad = tabs.copy()
+        bad[3, pos[3] // bs] = nb
+        with pytest.raises(nv.NvkError) as e:
+            a.append_batch(0, k, v, bad, pos)
+        assert e.value.code == nv._capi.ERR_BAD_BLOCK
+
+
+def test_ragged_batch_against_checker():
+    """A small ragged, fragmented batch (config-3 shape in miniature), every sequence checked."""
+    g = wl.Geometry(32, 8, 128, 16)
+    ctx = np.array([1, 7, 16, 17, 100, 255, 256, 257, 700, 1, 33, 513, 0, 64], np.int32)
+    work = wl.fragmented_workload("mini_ragged", ctx, g)
+    q = work.q()
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(work.num_seqs)))
+        want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, g.block_size, g.n_kv_heads)
+        for flags, chunk in ((nv.AUTO, 0), (nv.SINGLE_PASS, 0), (nv.SPLIT_K, 128), (nv.SPLIT_K, 40)):
+            got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, flags, chunk)
+            assert_close(got, want, f"flags={flags} chunk={chunk}")
+        assert not got[12].any()  # ctx 0: the reference zeroes out and does nothing else (attention.hpp:98)
+
+
+def test_bad_block_table_is_rejected_not_dereferenced():
+    with nv.PagedKVPool(1, 8, 16, 2, 64) as pool:
+        q = np.zeros((1, 4, 64), np.float32)
+        with pytest.raises(nv.NvkError) as e:
+            nv.decode(pool, 0, q, np.array([[0, 8]], np.int32), np.array([20], np.int32))
+        assert e.value.code == nv._capi.ERR_BAD_BLOCK
+        with pytest.raises(nv.NvkError):
+            nv.decode(pool, 0, q, np.array([[0, -1]], np.int32), np.array([20], np.int32))
+        with pytest.raises(nv.NvkError):  # table row too short for the context
+            nv.decode(pool, 0, q, np.array([[0, 1]], np.int32), np.array([40], np.int32))
+        with pytest.raises(nv.NvkError):  # n_heads not a multiple of n_kv_heads
+            nv.decode(pool, 0, np.zeros((1, 3, 64), np.float32), np.array([[0, 1]], np.int32),
+                      np.array([20], np.int32))
+
+
+def test_scores_below_reference_floor_give_reference_nans():
+    """max_val starts at -1e10 (attention.hpp:126): if every score is below it the reference divides 0 by 0."""
+    H, KV, hd, bs, T = 2, 1, 64, 16, 5
+    k_pool = np.full((1, bs, KV, hd), -1.0e6, np.float32)
+    v_pool = np.ones((1, bs, KV, hd), np.float32)
+    q = np.full((H, hd), 1.0e6, np.float32)
+    q[1] = 1.0  # head 1 stays in the normal range
+    table = np.array([0], np.int32)
+    want = ol.oracle_paged_attention(q, k_pool, v_pool, table, T, bs, hd, H, KV)
+    assert np.isnan(want[0]).all() and not np.isnan(want[1]).any()
+    with pool_from_host(k_pool, v_pool) as pool:
+        for flags, chunk in ((nv.SINGLE_PASS, 0), (nv.SPLIT_K, 8)):
+            got = nv.decode(pool, 0, q[None], table[None], np.array([T], np.int32), flags, chunk)[0]
+            assert_close(got, want, f"flags={flags}")
+
+
+def test_online_softmax_rescale_is_forced():
+    """A late, dominant key makes the running max jump mid-stream and across chunk boundaries."""
+    H, KV, hd, bs, T = 4, 1, 128, 16, 400
+    rng = np.random.default_rng(9)
+    nb = T // bs
+    k_pool = (0.05 * rng.standard_normal((nb, bs, KV, hd))).astype(np.float32)
+    v_pool = rng.standard_normal((nb, bs, KV, hd)).astype(np.float32)
+    q = rng.standard_normal((H, hd)).astype(np.float32)
+    for spike in (3, 130, 399):  # first step, a middle chunk, the very last token
+        k2 = k_pool.copy()
+        k2[spike // bs, spike % bs, 0] = 4.0 * q[0]  # score ~ +45 for head 0 only
+        table = np.arange(nb, dtype=np.int32)
+        want = ol.oracle_paged_attention(q, k2, v_pool, table, T, bs, hd, H, KV)
+        with pool_from_host(k2, v_pool) as pool:
+            for flags, chunk in ((nv.SINGLE_PASS, 0), (nv.SPLIT_K, 64), (nv.SPLIT_K, 8)):
+                got = nv.decode(pool, 0, q[None], table[None], np.array([T], np.int32), flags, chunk)[0]
+                assert_close(got, want, f"spike {spike} flags={flags} chunk={chunk}")
+
+
+def _full_size_check(work, sample, modes):
+    g = work.geom
+    q = work.q()
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, sample)
+    want = ol.oracle_decode_batch(q[sample], k_host, v_host, tabs, c, g.block_size, g.n_kv_heads, n_threads=8)
+    outs = []
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for flags, chunk in modes:
+            got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, flags, chunk)
+            assert_close(got[sample], want, f"{work.name} flags={flags} chunk={chunk}")
+            assert np.isfinite(got).all()
+            outs.append(got)
+        # size-independent property at full size: a softmax-weighted mean of V stays inside V's range
+        assert np.abs(outs[0]).max() <= 1.0
+        # and the split-K and single-pass answers agree everywhere, not just on the sampled sequences
+        for o in outs[1:]:
+            assert_close(o, outs[0], f"{work.name} mode agreement")
+        # permutation invariance: the same data behind a different physical placement gives the same bits
+        return outs[0]
+
+
+def test_config2_full_size():
+    """BASELINE.json configs[1]: 64 seqs x 2K ctx, uniform tables, 1 GiB of KV."""
+    work = wl.config2()
+    assert work.algorithmic_bytes() == 1_075_871_744
+    _full_size_check(work, [0, 1, 31, 62, 63], [(nv.AUTO, 0), (nv.SINGLE_PASS, 0), (nv.SPLIT_K, 256)])
+
+
+def test_config3_ragged_fragmented_full_size():
+    """configs[2]: 256 seqs, ctx 128..8192, fragmented tables."""
+    work = wl.config3()
+    order = np.argsort(work.ctx_lens)
+    sample = sorted({int(order[0]), int(order[1]), int(order[len(order) // 2]), int(order[-1]), 0, 255})
+    _full_size_check(work, sample, [(nv.AUTO, 0), (nv.SPLIT_K, 512)])
+
+
+def test_config4_long_context_split_k():
+    """configs[3]: 16 seqs x 32K ctx; split-K against single-pass and the checker."""
+    work = wl.config4()
+    _full_size_check(work, [0, 15], [(nv.AUTO, 0), (nv.SINGLE_PASS, 0), (nv.SPLIT_K, 1024)])
+
+
+def test_config5a_many_short_sequences():
+    """configs[4] (one GPU's share of 5a): 512 short sequences, ctx 64..192."""
+    work = wl.config5a(512)
+    _full_size_check(work, list(range(0, 512, 37)), [(nv.AUTO, 0), (nv.SINGLE_PASS, 0)])
+
+
+def test_block_placement_does_not_change_bits():
+    """Paged == contiguous: moving the same rows to other physical blocks leaves every output bit unchanged."""
+    case = ATTENTION_CASES[8]  # 32/8/128, 2048 tokens
+    q, k_pool, v_pool, table = attention_case_inputs(case)
+    T, bs = case["num_tokens"], case["block_size"]
+    nb = k_pool.shape[0]
+    ident = np.arange((T + bs - 1) // bs, dtype=np.int32)
+    k_lin = np.zeros_like(k_pool)
+    v_lin = np.zeros_like(v_pool)
+    k_lin[: ident.size] = k_pool[table[: ident.size]]
+    v_lin[: ident.size] = v_pool[table[: ident.size]]
+    ctx = np.array([T], np.int32)
+    with pool_from_host(k_pool, v_pool) as a, pool_from_host(k_lin, v_lin) as b:
+        for flags, chunk in ((nv.SINGLE_PASS, 0), (nv.SPLIT_K, 256)):
+            oa = nv.decode(a, 0, q[None], table[None], ctx, flags, chunk)
+            ob = nv.decode(b, 0, q[None], ident[None], ctx, flags, chunk)
+            assert np.array_equal(oa.view(np.uint32), ob.view(np.uint32))
+    assert nb > ident.size
