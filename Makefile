@@ -23,9 +23,9 @@ $(LIB): $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_kernels.hip.h $(CSRC)/nvk_block_m
 
 # device assembly + register/occupancy report for the kernels (not needed to run)
 asm:
-	mkdir -p build
+	mkdir -p build/asm
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) -save-temps=obj -c \
-	   -Rpass-analysis=kernel-resource-usage -o build/nvk_paged_attn.o $(CSRC)/nvk_paged_attn.hip 2> build/resource_usage.txt
+	   -Rpass-analysis=kernel-resource-usage -o build/asm/nvk_paged_attn.o $(CSRC)/nvk_paged_attn.hip 2> build/resource_usage.txt
 
 oracle:
 	$(MAKE) -C oracle oracle

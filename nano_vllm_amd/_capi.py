@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvk_paged_attn.so")
+# NVK_LIB_PATH selects another build of the same library (kernel-tuning experiments: tools/build_variants.sh)
+LIB_PATH = os.environ.get("NVK_LIB_PATH") or os.path.join(_HERE, "libnvk_paged_attn.so")
 
 OK = 0
 ERR_INVALID_ARG = -1

@@ -31,9 +31,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- build-time tuning knobs (defaults are the measured best) ----
+#ifndef NVK_STEP_TOKENS
+#define NVK_STEP_TOKENS 8 // tokens per wave per pipeline step: 4 token slots x (NVK_STEP_TOKENS/4) each
+#endif
+#ifndef NVK_MIN_WAVES_PER_EU
+#define NVK_MIN_WAVES_PER_EU 1 // __launch_bounds__ second argument (caps VGPRs: 2 -> 256, 3 -> 168, 4 -> 128)
+#endif
+#ifndef NVK_NT_LOADS
+#define NVK_NT_LOADS 1 // 1: K/V loads carry the non-temporal hint (read-once stream)
+#endif
+#ifndef NVK_FUSED_MERGE
+#define NVK_FUSED_MERGE 0 // 1: the last workgroup of a sequence merges its split-K partials in-launch (measured slower: DESIGN.md)
+#endif
+#ifndef NVK_ROTATE_START
+#define NVK_ROTATE_START 0 // 1: each workgroup starts its chunk at a different step (de-phases HBM channels)
+#endif
+
 namespace nvk {
 
-constexpr int   kStepTokens = 8;        // tokens per wave per pipeline step (2 quads)
+constexpr int   kStepTokens = NVK_STEP_TOKENS; // tokens per wave per pipeline step
+constexpr int   kTokPerLane = kStepTokens / 4; // tokens each lane holds per step
+static_assert(kStepTokens % 4 == 0 && kStepTokens >= 4, "a step is whole token quads");
 constexpr float kNegBig     = -1.0e30f; // running-max seed: finite, so exp2(m - m) never sees inf - inf
 // The reference seeds its max with -1e10 (attention.hpp:126); in the exp2
 // domain that floor is -1e10 * log2(e).
@@ -49,6 +68,7 @@ struct DecodeParams
     float       *out;          // [num_seqs, n_heads, head_dim]
     float       *ws_o;         // [num_seqs, max_chunks, n_heads, head_dim]  unnormalised partial outputs
     float       *ws_ml;        // [num_seqs, max_chunks, n_heads, 2]         (running max, running sum)
+    unsigned    *ws_arrivals;  // [num_seqs, gridDim.z] split-K arrival tickets; zero between launches
     int          max_blocks;
     int          num_blocks;
     int          block_size;
@@ -110,16 +130,27 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b, float ac
 
 template <int VPL> struct KVTile
 {
-    float4 k[2][VPL];
-    float4 v[2][VPL];
+    float4 k[kTokPerLane][VPL];
+    float4 v[kTokPerLane][VPL];
 };
+
+__device__ __forceinline__ float4 load_kv(const float *p)
+{
+#if NVK_NT_LOADS
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
 
 // ---- the decode kernel ----------------------------------------------------
 // VPL   float4 per lane per row (head_dim <= 64*VPL)
 // QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.z also walks kv_mul/QPK)
 // FULL  head_dim == 64*VPL, so no lane is idle and no load needs a predicate
 template <int VPL, int QPK, bool FULL>
-__global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
+__global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(const DecodeParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice
 
@@ -149,7 +180,7 @@ __global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
 
     if (ctx <= 0) {
         // the reference zeroes `out` before anything else (attention.hpp:98)
-        if (p.max_chunks == 1 && chunk == 0 && live && slot == 0) {
+        if ((p.max_chunks == 1 || NVK_FUSED_MERGE) && chunk == 0 && live && slot == 0) {
 #pragma unroll
             for (int h = 0; h < QPK; h++)
 #pragma unroll
@@ -169,8 +200,23 @@ __global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
     for (int i = threadIdx.x; i <= blk1 - blk0; i += blockDim.x)
         s_tab[i] = clamp_block(p.block_tables[(int64_t)seq * p.max_blocks + blk0 + i], p.num_blocks);
     __syncthreads();
+#if !NVK_FUSED_MERGE
     if (!live)
         return; // no barrier after this point
+#endif
+
+    float  m[QPK], l[QPK];
+    float4 o[QPK][VPL];
+#pragma unroll
+    for (int h = 0; h < QPK; h++) {
+        m[h] = kNegBig;
+        l[h] = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; j++)
+            o[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    if (live) { // ---- stream this wave's kv-head over the chunk (wave-uniform branch) ----
 
     // q for this wave's q-heads, pre-scaled into the exp2 domain
     float4 qv[QPK][VPL];
@@ -185,24 +231,13 @@ __global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
             qv[h][j] = make_float4(t.x * p.q_scale, t.y * p.q_scale, t.z * p.q_scale, t.w * p.q_scale);
         }
 
-    float  m[QPK], l[QPK];
-    float4 o[QPK][VPL];
-#pragma unroll
-    for (int h = 0; h < QPK; h++) {
-        m[h] = kNegBig;
-        l[h] = 0.f;
-#pragma unroll
-        for (int j = 0; j < VPL; j++)
-            o[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-
     const int lane_col = kvh * hd + 4 * r; // float offset of this lane inside a token row
     const int row_len  = p.n_kv_heads * hd;
 
     auto load_tile = [&](KVTile<VPL> &T, int ts) {
-        int64_t at[2];
+        int64_t at[kTokPerLane];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < kTokPerLane; i++) {
             const int tok = min(ts + 4 * i + slot, t1 - 1); // past-the-end lanes re-read the last row
             const int blk = token_block(tok, p.block_size, p.bs_shift);
             const int off = token_offset(tok, blk, p.block_size, p.bs_shift);
@@ -210,27 +245,27 @@ __global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
             at[i]         = ((int64_t)pb * p.block_size + off) * row_len + lane_col;
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < kTokPerLane; i++)
 #pragma unroll
             for (int j = 0; j < VPL; j++) {
                 T.k[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act[j])
-                    T.k[i][j] = *reinterpret_cast<const float4 *>(p.k_layer + at[i] + 64 * j);
+                    T.k[i][j] = load_kv(p.k_layer + at[i] + 64 * j);
             }
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < kTokPerLane; i++)
 #pragma unroll
             for (int j = 0; j < VPL; j++) {
                 T.v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act[j])
-                    T.v[i][j] = *reinterpret_cast<const float4 *>(p.v_layer + at[i] + 64 * j);
+                    T.v[i][j] = load_kv(p.v_layer + at[i] + 64 * j);
             }
     };
 
     auto consume_tile = [&](const KVTile<VPL> &T, int ts) {
-        float s[2][QPK];
+        float s[kTokPerLane][QPK];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < kTokPerLane; i++) {
             const bool in_range = ts + 4 * i + slot < t1;
 #pragma unroll
             for (int h = 0; h < QPK; h++) {
@@ -244,40 +279,64 @@ __global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
         }
 #pragma unroll
         for (int h = 0; h < QPK; h++) {
-            const float mn    = fmaxf(m[h], fmaxf(s[0][h], s[1][h]));
+            float mn = m[h];
+#pragma unroll
+            for (int i = 0; i < kTokPerLane; i++)
+                mn = fmaxf(mn, s[i][h]);
             const float alpha = fast_exp2(m[h] - mn);
-            const float p0    = fast_exp2(s[0][h] - mn);
-            const float p1    = fast_exp2(s[1][h] - mn);
-            m[h]              = mn;
-            l[h]              = fmaf(l[h], alpha, p0 + p1);
+            float       pw[kTokPerLane];
+            float       psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < kTokPerLane; i++) {
+                pw[i] = fast_exp2(s[i][h] - mn);
+                psum += pw[i];
+            }
+            m[h] = mn;
+            l[h] = fmaf(l[h], alpha, psum);
 #pragma unroll
             for (int j = 0; j < VPL; j++) {
                 float4 a = o[h][j];
-                a.x      = fmaf(a.x, alpha, fmaf(p0, T.v[0][j].x, p1 * T.v[1][j].x));
-                a.y      = fmaf(a.y, alpha, fmaf(p0, T.v[0][j].y, p1 * T.v[1][j].y));
-                a.z      = fmaf(a.z, alpha, fmaf(p0, T.v[0][j].z, p1 * T.v[1][j].z));
-                a.w      = fmaf(a.w, alpha, fmaf(p0, T.v[0][j].w, p1 * T.v[1][j].w));
-                o[h][j]  = a;
+                a.x *= alpha, a.y *= alpha, a.z *= alpha, a.w *= alpha;
+#pragma unroll
+                for (int i = 0; i < kTokPerLane; i++) {
+                    a.x = fmaf(pw[i], T.v[i][j].x, a.x);
+                    a.y = fmaf(pw[i], T.v[i][j].y, a.y);
+                    a.z = fmaf(pw[i], T.v[i][j].z, a.z);
+                    a.w = fmaf(pw[i], T.v[i][j].w, a.w);
+                }
+                o[h][j] = a;
             }
         }
     };
 
-    // two named tiles, hand-unrolled by two, so no register copies and no runtime-indexed arrays
+    // Two named tiles, hand-unrolled by two: no register copies, no runtime-indexed arrays.
+    // Steps are visited in rotated order when NVK_ROTATE_START is set (softmax is order-free):
+    // step index k = 0..nsteps-1 maps to token offset ((k + rot) % nsteps) * kStepTokens.
+    const int nsteps = (t1 - t0 + kStepTokens - 1) / kStepTokens;
+#if NVK_ROTATE_START
+    const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u + blockIdx.z) % (unsigned)nsteps);
+#else
+    const int rot = 0;
+#endif
+    auto step_token = [&](int k) {
+        int idx = k + rot;
+        if (idx >= nsteps)
+            idx -= nsteps;
+        return t0 + idx * kStepTokens;
+    };
     KVTile<VPL> ta, tb;
-    int         ts = t0;
-    load_tile(ta, ts);
+    int         k = 0;
+    load_tile(ta, step_token(0));
     for (;;) {
-        if (ts + kStepTokens < t1)
-            load_tile(tb, ts + kStepTokens);
-        consume_tile(ta, ts);
-        ts += kStepTokens;
-        if (ts >= t1)
+        if (k + 1 < nsteps)
+            load_tile(tb, step_token(k + 1));
+        consume_tile(ta, step_token(k));
+        if (++k >= nsteps)
             break;
-        if (ts + kStepTokens < t1)
-            load_tile(ta, ts + kStepTokens);
-        consume_tile(tb, ts);
-        ts += kStepTokens;
-        if (ts >= t1)
+        if (k + 1 < nsteps)
+            load_tile(ta, step_token(k + 1));
+        consume_tile(tb, step_token(k));
+        if (++k >= nsteps)
             break;
     }
 
@@ -304,24 +363,32 @@ __global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
         }
     }
 
-    if (slot != 0)
-        return;
+    } // live
 
-    if (p.max_chunks == 1) {
+    // How many chunks this sequence really has decides where the result goes.
+    const int  nch    = (ctx + p.chunk_tokens - 1) / p.chunk_tokens;
+    const bool direct = p.max_chunks == 1 || (NVK_FUSED_MERGE && nch == 1);
+
+    if (direct) {
+        if (live && slot == 0) {
 #pragma unroll
-        for (int h = 0; h < QPK; h++) {
-            // reference: max_val = max(-1e10, scores) (attention.hpp:126-130); a no-op unless every score is below it
-            const float mf  = fmaxf(m[h], kRefMaxFloorLog2);
-            const float f   = fast_exp2(m[h] - mf);
-            const float inv = f / (l[h] * f);
+            for (int h = 0; h < QPK; h++) {
+                // reference: max_val = max(-1e10, scores) (attention.hpp:126-130); a no-op unless every score is below it
+                const float mf  = fmaxf(m[h], kRefMaxFloorLog2);
+                const float f   = fast_exp2(m[h] - mf);
+                const float inv = f / (l[h] * f);
 #pragma unroll
-            for (int j = 0; j < VPL; j++)
-                if (act[j])
-                    *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
-                        make_float4(o[h][j].x * inv, o[h][j].y * inv, o[h][j].z * inv, o[h][j].w * inv);
+                for (int j = 0; j < VPL; j++)
+                    if (act[j])
+                        *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j
+                                                    + 4 * r) =
+                            make_float4(o[h][j].x * inv, o[h][j].y * inv, o[h][j].z * inv, o[h][j].w * inv);
+            }
         }
+        return;
     }
-    else {
+
+    if (live && slot == 0) {
         const int64_t item = (int64_t)seq * p.max_chunks + chunk;
 #pragma unroll
         for (int h = 0; h < QPK; h++) {
@@ -334,6 +401,69 @@ __global__ void __launch_bounds__(512) nvk_decode_kernel(const DecodeParams p)
                 *reinterpret_cast<float2 *>(p.ws_ml + (item * p.n_heads + qh0 + h) * 2) = make_float2(m[h], l[h]);
         }
     }
+
+#if NVK_FUSED_MERGE
+    // ---- in-launch split-K combine (cdna_hip_programming.md section 5 "In-launch split-K reduction") ----
+    // Publish: every storing wave drains its stores, the workgroup meets, ONE lane does an
+    // agent-scope release and draws a ticket.  The workgroup that draws the sequence's last
+    // ticket acquires (agent scope, one lane), the workgroup meets again, and all its waves
+    // merge every chunk's partial, in chunk order, so the result does not depend on which
+    // workgroup happens to be last.  Placement (XCD, CU, dispatch order) plays no part.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads(); // also: nobody reads s_tab[] any more, so word 0 can carry the verdict
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned *ticket = p.ws_arrivals + (int64_t)seq * gridDim.z + blockIdx.z;
+        const unsigned drawn =
+            __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = drawn == (unsigned)(nch - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // leave the ticket word zero for the next launch (a kernel boundary orders this store)
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_tab[0] = last;
+    }
+    __syncthreads();
+    if (!s_tab[0])
+        return;
+
+    // one work item = (wave's kv-head, q-head of it, float4 of head_dim); same maths as nvk_merge_kernel
+    const int vec_row = hd >> 2;
+    const int items   = nwaves * QPK * vec_row;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int w   = it / (QPK * vec_row);
+        const int rem = it - w * (QPK * vec_row);
+        const int h   = rem / vec_row;
+        const int vec = rem - h * vec_row;
+        const int kv2 = (blockIdx.z / qsplit) * nwaves + w;
+        if (kv2 >= p.n_kv_heads)
+            continue;
+        const int    head = kv2 * p.kv_mul + zq * QPK + h;
+        const float *ml   = p.ws_ml + ((int64_t)seq * p.max_chunks * p.n_heads + head) * 2;
+        const float *po   = p.ws_o + ((int64_t)seq * p.max_chunks * p.n_heads + head) * hd + 4 * vec;
+        float        top  = kRefMaxFloorLog2;
+        for (int c = 0; c < nch; c++)
+            top = fmaxf(top, ml[(int64_t)c * p.n_heads * 2]);
+        float  denom = 0.f;
+        float4 acc   = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < nch; c++) {
+            const float2 sc = *reinterpret_cast<const float2 *>(ml + (int64_t)c * p.n_heads * 2);
+            const float  f  = fast_exp2(sc.x - top);
+            const float4 a  = *reinterpret_cast<const float4 *>(po + (int64_t)c * p.n_heads * hd);
+            denom           = fmaf(sc.y, f, denom);
+            acc.x           = fmaf(a.x, f, acc.x);
+            acc.y           = fmaf(a.y, f, acc.y);
+            acc.z           = fmaf(a.z, f, acc.z);
+            acc.w           = fmaf(a.w, f, acc.w);
+        }
+        const float inv = 1.0f / denom;
+        *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + head) * hd + 4 * vec) =
+            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+#endif
 }
 
 // ---- split-K merge (flash-decoding combine) ---------------------------------

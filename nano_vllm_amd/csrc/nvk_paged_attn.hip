@@ -18,6 +18,10 @@
 
 #define NVK_VERSION_STRING "nvk_paged_attn 0.1.0 (gfx950)"
 
+#ifndef NVK_WG_WAVES
+#define NVK_WG_WAVES 8 // kv-heads (= waves) per workgroup, at most
+#endif
+
 // ------------------------------------------------------------------ errors
 namespace nvk {
 
@@ -87,8 +91,9 @@ struct nvk_pool
     int         num_cus = 256;
 
     // split-K workspace (grown on demand, reused across calls)
-    float *ws_o = nullptr, *ws_ml = nullptr;
-    size_t ws_o_floats = 0, ws_ml_floats = 0;
+    float    *ws_o = nullptr, *ws_ml = nullptr;
+    unsigned *ws_arrivals = nullptr; // split-K tickets; every launch leaves them zero again
+    size_t    ws_o_floats = 0, ws_ml_floats = 0, ws_arrival_words = 0;
 
     // staging for the host-pointer entry points
     char  *stage     = nullptr;
@@ -119,11 +124,23 @@ int ensure_stage(nvk_pool *pool, size_t bytes)
     return NVK_OK;
 }
 
-int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
+int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats, size_t arrival_words)
 {
+    if (arrival_words > pool->ws_arrival_words) {
+        if (pool->ws_arrivals) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(pool->ws_arrivals));
+            pool->ws_arrivals      = nullptr;
+            pool->ws_arrival_words = 0;
+        }
+        const size_t words = (arrival_words + 63) / 64 * 64;
+        HIP_TRY(hipMalloc(&pool->ws_arrivals, words * sizeof(unsigned)));
+        HIP_TRY(hipMemset(pool->ws_arrivals, 0, words * sizeof(unsigned))); // synchronous: ordered before any stream's launch
+        pool->ws_arrival_words = words;
+    }
     if (o_floats > pool->ws_o_floats) {
         if (pool->ws_o) {
-            HIP_TRY(hipStreamSynchronize(pool->stream));
+            HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipFree(pool->ws_o));
             pool->ws_o        = nullptr;
             pool->ws_o_floats = 0;
@@ -133,7 +150,7 @@ int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
     }
     if (ml_floats > pool->ws_ml_floats) {
         if (pool->ws_ml) {
-            HIP_TRY(hipStreamSynchronize(pool->stream));
+            HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipFree(pool->ws_ml));
             pool->ws_ml        = nullptr;
             pool->ws_ml_floats = 0;
@@ -183,7 +200,7 @@ int make_plan(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int 
     plan->qpk        = kv_mul % 4 == 0 ? 4 : (kv_mul % 2 == 0 ? 2 : 1);
     if (plan->vpl == 4 && plan->qpk == 4)
         plan->qpk = 2; // 4 q-heads x 16 floats of q and o per lane would spill
-    plan->waves      = std::min(pool->n_kv_heads, 8);
+    plan->waves      = std::min(pool->n_kv_heads, NVK_WG_WAVES);
     plan->kv_groups  = (pool->n_kv_heads + plan->waves - 1) / plan->waves;
 
     const int step    = nvk::kStepTokens;
@@ -199,13 +216,14 @@ int make_plan(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int 
         chunk = round_up(chunk_tokens, step);
     }
     else {
-        // AUTO (and SPLIT_K with no size): enough workgroups to fill every CU a few
-        // times over, but chunks no shorter than 128 tokens so the per-chunk
-        // prologue/epilogue stays small against the streaming loop.
-        const long long target_wgs = (long long)pool->num_cus * 8;
-        const long long per_chunk  = std::max<long long>(1, (long long)num_seqs * plan->kv_groups * (kv_mul / plan->qpk));
-        long long       chunks_per_seq = std::max<long long>(1, target_wgs / per_chunk);
-        chunk                          = round_up((int)std::max<long long>(128, (ctx_cap + chunks_per_seq - 1) / chunks_per_seq), step);
+        // AUTO (and SPLIT_K with no size).  Measured on config 2 (profiles/): a workgroup should
+        // stream as long a chunk as possible while the grid still covers every CU about once
+        // (8 waves at 192 VGPRs = one workgroup per CU); 1024 tokens caps the imbalance a
+        // ragged batch can suffer, 128 keeps the per-chunk prologue/epilogue small.
+        const long long wg_per_chunk = std::max<long long>(1, (long long)plan->kv_groups * (kv_mul / plan->qpk));
+        const long long tokens_upper = (long long)num_seqs * ctx_cap * wg_per_chunk;
+        chunk = round_up((int)std::min<long long>(1 << 20, (tokens_upper + pool->num_cus - 1) / pool->num_cus), 128);
+        chunk = std::max<long long>(128, std::min<long long>(chunk, 1024));
     }
     chunk = std::min<long long>(chunk, ctx_cap);
     chunk = std::min<long long>(chunk, slice_cap);
@@ -268,9 +286,10 @@ int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const f
         return nvk::fail(NVK_ERR_INVALID_ARG, "num_seqs=%d exceeds the grid's y extent (65535)", num_seqs);
 
     const int kv_mul = n_heads / pool->n_kv_heads;
+    const unsigned grid_z = (unsigned)(plan.kv_groups * (kv_mul / plan.qpk));
     if (plan.max_chunks > 1) {
         rc = ensure_workspace(pool, (size_t)num_seqs * plan.max_chunks * n_heads * pool->head_dim,
-                              (size_t)num_seqs * plan.max_chunks * n_heads * 2);
+                              (size_t)num_seqs * plan.max_chunks * n_heads * 2, (size_t)num_seqs * grid_z);
         if (rc != NVK_OK)
             return rc;
     }
@@ -284,6 +303,7 @@ int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const f
     p.out          = out_dev;
     p.ws_o         = pool->ws_o;
     p.ws_ml        = pool->ws_ml;
+    p.ws_arrivals  = pool->ws_arrivals;
     p.max_blocks   = max_blocks;
     p.num_blocks   = pool->num_blocks;
     p.block_size   = pool->block_size;
@@ -296,7 +316,7 @@ int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const f
     p.max_chunks   = plan.max_chunks;
     p.q_scale      = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
 
-    const dim3 grid((unsigned)plan.max_chunks, (unsigned)num_seqs, (unsigned)(plan.kv_groups * (kv_mul / plan.qpk)));
+    const dim3 grid((unsigned)plan.max_chunks, (unsigned)num_seqs, grid_z);
     const dim3 block((unsigned)plan.waves * 64);
     if (ev_attn_begin)
         HIP_TRY(hipEventRecord(ev_attn_begin, stream));
@@ -304,7 +324,7 @@ int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const f
     if (ev_attn_end)
         HIP_TRY(hipEventRecord(ev_attn_end, stream));
 
-    if (plan.max_chunks > 1) {
+    if (plan.max_chunks > 1 && !NVK_FUSED_MERGE) {
         const int  vecs = n_heads * (pool->head_dim / 4);
         const dim3 mgrid((unsigned)((vecs + 255) / 256), (unsigned)num_seqs);
         hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml, ctx_dev, out_dev,
@@ -414,6 +434,8 @@ int nvk_pool_destroy(nvk_pool *pool)
         (void)hipFree(pool->ws_o);
     if (pool->ws_ml)
         (void)hipFree(pool->ws_ml);
+    if (pool->ws_arrivals)
+        (void)hipFree(pool->ws_arrivals);
     if (pool->stage)
         (void)hipFree(pool->stage);
     if (pool->ev_a)
@@ -647,8 +669,10 @@ int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int ma
                        chunk_tokens, &plan);
     if (rc != NVK_OK)
         return rc;
+    const int kv_mul = n_heads / pool->n_kv_heads;
     return ensure_workspace(pool, (size_t)num_seqs * plan.max_chunks * n_heads * pool->head_dim,
-                            (size_t)num_seqs * plan.max_chunks * n_heads * 2);
+                            (size_t)num_seqs * plan.max_chunks * n_heads * 2,
+                            (size_t)num_seqs * plan.kv_groups * (kv_mul / plan.qpk));
 }
 
 int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
