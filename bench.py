@@ -43,6 +43,16 @@ def make_workload(name):
         return wl.config3()
     if name == "config4":
         return wl.config4()
+    if name == "config3u":  # diagnostic: config 3's ragged lengths behind contiguous tables
+        w = wl.config3()
+        need = (w.ctx_lens.astype(np.int64) + w.geom.block_size - 1) // w.geom.block_size
+        start = np.concatenate([[0], np.cumsum(need)[:-1]])
+        tabs = np.zeros_like(w.block_tables)
+        for s in range(w.num_seqs):
+            tabs[s, :need[s]] = start[s] + np.arange(need[s])
+        return wl.Workload("decode_256xragged_contiguous", w.geom, int(need.sum()), w.ctx_lens, tabs)
+    if name == "config2f":  # diagnostic: config 2's uniform lengths behind fragmented tables
+        return wl.fragmented_workload("decode_64x2048_fragmented", np.full(64, 2048, np.int32))
     if name == "5a":
         return wl.config5a(512)
     if name == "5b":

@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 // ---- build-time tuning knobs (defaults are the measured best) ----
 #ifndef NVK_STEP_TOKENS
 #define NVK_STEP_TOKENS 8 // tokens per wave per pipeline step: 4 token slots x (NVK_STEP_TOKENS/4) each
@@ -41,11 +43,16 @@
 #ifndef NVK_NT_LOADS
 #define NVK_NT_LOADS 1 // 1: K/V loads carry the non-temporal hint (read-once stream)
 #endif
+#ifndef NVK_SCHED_BARRIER
+#define NVK_SCHED_BARRIER 0 // 1: pin "issue next tile" ahead of "consume current tile" with sched_barrier(0)
+#endif
+#if NVK_SCHED_BARRIER
+#define NVK_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NVK_PIN() ((void)0)
+#endif
 #ifndef NVK_FUSED_MERGE
 #define NVK_FUSED_MERGE 0 // 1: the last workgroup of a sequence merges its split-K partials in-launch (measured slower: DESIGN.md)
-#endif
-#ifndef NVK_ROTATE_START
-#define NVK_ROTATE_START 0 // 1: each workgroup starts its chunk at a different step (de-phases HBM channels)
 #endif
 
 namespace nvk {
@@ -72,7 +79,7 @@ struct DecodeParams
     int          max_blocks;
     int          num_blocks;
     int          block_size;
-    int          bs_shift; // log2(block_size), or -1 when block_size is not a power of two
+    unsigned     bs_magic; // ceil(2^32 / block_size); 0 for block_size 1 (see token_block)
     int          n_kv_heads;
     int          n_heads;
     int          kv_mul; // n_heads / n_kv_heads
@@ -83,14 +90,14 @@ struct DecodeParams
 };
 
 // ---- address arithmetic shared by decode, gather and append ---------------
-__device__ __forceinline__ int token_block(int tok, int block_size, int bs_shift)
+// t / block_size without a divide and without a branch: bs_magic = ceil(2^32 / block_size),
+// exact for t < 2^32 / block_size (checked on the host); block_size 1 has magic 0 (2^32 does not fit).
+__device__ __forceinline__ int token_block(int tok, unsigned bs_magic)
 {
-    return bs_shift >= 0 ? (tok >> bs_shift) : (tok / block_size);
+    const unsigned whole = bs_magic ? 0u : 0xFFFFFFFFu; // uniform; keeps the lane code branch-free
+    return (int)(__umulhi((unsigned)tok, bs_magic) + ((unsigned)tok & whole));
 }
-__device__ __forceinline__ int token_offset(int tok, int blk, int block_size, int bs_shift)
-{
-    return bs_shift >= 0 ? (tok & (block_size - 1)) : (tok - blk * block_size);
-}
+__device__ __forceinline__ int token_offset(int tok, int blk, int block_size) { return tok - blk * block_size; }
 // float index of element 0 of (physical block, offset, kv head) inside a layer slab
 __device__ __forceinline__ int64_t row_float_index(int physical_block, int block_offset, int kv_head,
                                                    int block_size, int n_kv_heads, int head_dim)
@@ -195,8 +202,8 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         return; // whole workgroup: this sequence has fewer chunks than the grid is wide
 
     const int t1   = min(t0 + p.chunk_tokens, ctx);
-    const int blk0 = token_block(t0, p.block_size, p.bs_shift);
-    const int blk1 = token_block(t1 - 1, p.block_size, p.bs_shift);
+    const int blk0 = token_block(t0, p.bs_magic);
+    const int blk1 = token_block(t1 - 1, p.bs_magic);
     for (int i = threadIdx.x; i <= blk1 - blk0; i += blockDim.x)
         s_tab[i] = clamp_block(p.block_tables[(int64_t)seq * p.max_blocks + blk0 + i], p.num_blocks);
     __syncthreads();
@@ -238,9 +245,10 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         int64_t at[kTokPerLane];
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++) {
-            const int tok = min(ts + 4 * i + slot, t1 - 1); // past-the-end lanes re-read the last row
-            const int blk = token_block(tok, p.block_size, p.bs_shift);
-            const int off = token_offset(tok, blk, p.block_size, p.bs_shift);
+            // lanes past the chunk's end (last step only) re-read its last row; consume_tile masks their scores
+            const int tok = min(ts + 4 * i + slot, t1 - 1);
+            const int blk = token_block(tok, p.bs_magic);
+            const int off = token_offset(tok, blk, p.block_size);
             const int pb  = s_tab[blk - blk0];
             at[i]         = ((int64_t)pb * p.block_size + off) * row_len + lane_col;
         }
@@ -262,11 +270,13 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
             }
     };
 
-    auto consume_tile = [&](const KVTile<VPL> &T, int ts) {
-        float s[kTokPerLane][QPK];
+    // TAIL = false: every token of the step is inside the chunk, no masking needed
+    auto consume_tile = [&](const KVTile<VPL> &T, int ts, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
+        float          s[kTokPerLane][QPK];
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++) {
-            const bool in_range = ts + 4 * i + slot < t1;
+            const bool in_range = !TAIL || (ts + 4 * i + slot < t1);
 #pragma unroll
             for (int h = 0; h < QPK; h++) {
                 float acc = 0.f;
@@ -309,35 +319,33 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         }
     };
 
-    // Two named tiles, hand-unrolled by two: no register copies, no runtime-indexed arrays.
-    // Steps are visited in rotated order when NVK_ROTATE_START is set (softmax is order-free):
-    // step index k = 0..nsteps-1 maps to token offset ((k + rot) % nsteps) * kStepTokens.
+    // Software pipeline over steps of kStepTokens tokens: two named tiles, hand-unrolled by two
+    // (no register copies, no runtime-indexed arrays).  The steady-state loop prefetches
+    // unconditionally, so every path into a consume has the same number of loads in flight and
+    // hipcc can emit counted vmcnt waits that leave the whole next tile outstanding; the last one
+    // or two steps (the only ones that can run past the chunk's end) are peeled off.
+    const std::integral_constant<bool, false> body;
+    const std::integral_constant<bool, true>  tail;
     const int nsteps = (t1 - t0 + kStepTokens - 1) / kStepTokens;
-#if NVK_ROTATE_START
-    const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u + blockIdx.z) % (unsigned)nsteps);
-#else
-    const int rot = 0;
-#endif
-    auto step_token = [&](int k) {
-        int idx = k + rot;
-        if (idx >= nsteps)
-            idx -= nsteps;
-        return t0 + idx * kStepTokens;
-    };
     KVTile<VPL> ta, tb;
     int         k = 0;
-    load_tile(ta, step_token(0));
-    for (;;) {
-        if (k + 1 < nsteps)
-            load_tile(tb, step_token(k + 1));
-        consume_tile(ta, step_token(k));
-        if (++k >= nsteps)
-            break;
-        if (k + 1 < nsteps)
-            load_tile(ta, step_token(k + 1));
-        consume_tile(tb, step_token(k));
-        if (++k >= nsteps)
-            break;
+    load_tile(ta, t0);
+    for (; k + 2 < nsteps; k += 2) {
+        load_tile(tb, t0 + (k + 1) * kStepTokens);
+        NVK_PIN(); // issue the whole next tile before any wait on the current one
+        consume_tile(ta, t0 + k * kStepTokens, body);
+        load_tile(ta, t0 + (k + 2) * kStepTokens);
+        NVK_PIN();
+        consume_tile(tb, t0 + (k + 1) * kStepTokens, body);
+    }
+    if (nsteps - k == 2) {
+        load_tile(tb, t0 + (k + 1) * kStepTokens);
+        NVK_PIN();
+        consume_tile(ta, t0 + k * kStepTokens, body);
+        consume_tile(tb, t0 + (k + 1) * kStepTokens, tail);
+    }
+    else {
+        consume_tile(ta, t0 + k * kStepTokens, tail);
     }
 
     // merge the four token slots of the wave (lanes 16 and 32 apart)
@@ -517,14 +525,14 @@ __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict_
 // grid.x = tokens; copies K and V rows of one kv-head to [num_tokens, head_dim].
 __global__ void nvk_gather_kernel(const float *__restrict__ k_layer, const float *__restrict__ v_layer,
                                   const int *__restrict__ block_table, int num_tokens, int kv_head, int num_blocks,
-                                  int block_size, int bs_shift, int n_kv_heads, int head_dim,
+                                  int block_size, unsigned bs_magic, int n_kv_heads, int head_dim,
                                   float *__restrict__ k_out, float *__restrict__ v_out)
 {
     const int tok = blockIdx.x;
     if (tok >= num_tokens)
         return;
-    const int     blk = token_block(tok, block_size, bs_shift);
-    const int     off = token_offset(tok, blk, block_size, bs_shift);
+    const int     blk = token_block(tok, bs_magic);
+    const int     off = token_offset(tok, blk, block_size);
     const int     pb  = clamp_block(block_table[blk], num_blocks);
     const int64_t at  = row_float_index(pb, off, kv_head, block_size, n_kv_heads, head_dim);
     for (int d = threadIdx.x; d < head_dim; d += blockDim.x) {
@@ -539,15 +547,15 @@ __global__ void nvk_gather_kernel(const float *__restrict__ k_layer, const float
 __global__ void nvk_append_kernel(float *__restrict__ k_layer, float *__restrict__ v_layer,
                                   const float *__restrict__ k_rows, const float *__restrict__ v_rows,
                                   const int *__restrict__ block_tables, int max_blocks,
-                                  const int *__restrict__ positions, int num_blocks, int block_size, int bs_shift,
-                                  int row_len)
+                                  const int *__restrict__ positions, int num_blocks, int block_size,
+                                  unsigned bs_magic, int row_len)
 {
     const int seq = blockIdx.x;
     const int pos = positions[seq];
     if (pos < 0)
         return;
-    const int     blk = token_block(pos, block_size, bs_shift);
-    const int     off = token_offset(pos, blk, block_size, bs_shift);
+    const int     blk = token_block(pos, bs_magic);
+    const int     off = token_offset(pos, blk, block_size);
     const int     pb  = clamp_block(block_tables[(int64_t)seq * max_blocks + blk], num_blocks);
     const int64_t at  = ((int64_t)pb * block_size + off) * row_len;
     for (int i = threadIdx.x * 4; i < row_len; i += blockDim.x * 4) { // row_len % 4 == 0 (checked on the host)

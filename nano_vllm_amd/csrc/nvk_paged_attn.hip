@@ -66,14 +66,12 @@ struct DeviceScope
     }
 };
 
-int log2_exact(int v)
+// ceil(2^32 / block_size) for nvk::token_block; 0 stands for block_size 1
+unsigned division_magic(int block_size)
 {
-    if (v <= 0 || (v & (v - 1)))
-        return -1;
-    int s = 0;
-    while ((1 << s) < v)
-        s++;
-    return s;
+    if (block_size <= 1)
+        return 0u;
+    return (unsigned)(((1ULL << 32) + (unsigned)block_size - 1) / (unsigned)block_size);
 }
 
 int round_up(int v, int to) { return (v + to - 1) / to * to; }
@@ -84,7 +82,7 @@ int round_up(int v, int to) { return (v + to - 1) / to * to; }
 struct nvk_pool
 {
     int    n_layers = 0, num_blocks = 0, block_size = 0, n_kv_heads = 0, head_dim = 0, device = 0;
-    int    bs_shift     = -1;
+    unsigned bs_magic   = 0;
     size_t layer_floats = 0; // num_blocks * block_size * n_kv_heads * head_dim
     float *k = nullptr, *v = nullptr;
     hipStream_t stream = nullptr;
@@ -307,7 +305,7 @@ int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const f
     p.max_blocks   = max_blocks;
     p.num_blocks   = pool->num_blocks;
     p.block_size   = pool->block_size;
-    p.bs_shift     = pool->bs_shift;
+    p.bs_magic     = pool->bs_magic;
     p.n_kv_heads   = pool->n_kv_heads;
     p.n_heads      = n_heads;
     p.kv_mul       = kv_mul;
@@ -383,7 +381,7 @@ int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads
         return nvk::fail(NVK_ERR_OOM, "nvk_pool_create: host allocation failed");
     pool->n_layers = n_layers, pool->num_blocks = num_blocks, pool->block_size = block_size;
     pool->n_kv_heads = n_kv_heads, pool->head_dim = head_dim, pool->device = device;
-    pool->bs_shift     = log2_exact(block_size);
+    pool->bs_magic     = division_magic(block_size);
     pool->layer_floats = (size_t)num_blocks * block_size * n_kv_heads * head_dim;
 
     hipDeviceProp_t prop;
@@ -559,7 +557,7 @@ int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *
     }
     hipLaunchKernelGGL(nvk::nvk_append_kernel, dim3((unsigned)num_seqs), dim3(256), 0, pool->stream, pool->k_layer(layer),
                        pool->v_layer(layer), dk, dv, dt, max_blocks, dp, pool->num_blocks, pool->block_size,
-                       pool->bs_shift, row);
+                       pool->bs_magic, row);
     HIP_TRY(hipGetLastError());
     if (ptr_kind == NVK_PTR_HOST)
         HIP_TRY(hipStreamSynchronize(pool->stream));
@@ -633,7 +631,7 @@ int nvk_pool_gather(nvk_pool *pool, int layer, const int *block_table, int num_t
     int   *dt = (int *)(pool->stage + 2 * out_a);
     HIP_TRY(hipMemcpyAsync(dt, block_table, tab_b, hipMemcpyHostToDevice, pool->stream));
     hipLaunchKernelGGL(nvk::nvk_gather_kernel, dim3((unsigned)num_tokens), dim3(64), 0, pool->stream, pool->k_layer(layer),
-                       pool->v_layer(layer), dt, num_tokens, kv_head, pool->num_blocks, pool->block_size, pool->bs_shift,
+                       pool->v_layer(layer), dt, num_tokens, kv_head, pool->num_blocks, pool->block_size, pool->bs_magic,
                        pool->n_kv_heads, pool->head_dim, dk, dv);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(k_out, dk, out_b, hipMemcpyDeviceToHost, pool->stream));
