@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--mode", default="auto", choices=["auto", "single", "split"])
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--replan", type=int, default=1,
+                    help="rebuild the decode plan every N layer-calls inside the timed region "
+                         "(1 = every call; 32 = as for the 32 layers of one model step)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -180,7 +183,7 @@ def main():
 
     def run(warmup, iters):
         return nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
-                               flags, args.chunk, warmup, iters)
+                               flags, args.chunk, warmup, iters, replan_every=args.replan)
 
     def barrier():
         if world > 1:
@@ -220,7 +223,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": work.name, "num_seqs_per_gpu": work.num_seqs, "total_ctx_tokens_per_gpu":
                        work.total_tokens, "n_heads": g.n_heads, "n_kv_heads": g.n_kv_heads, "head_dim": g.head_dim,
-                       "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode,
+                       "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode, "replan_every": args.replan,
                        "parallelism": f"sequence-sharded x{world}, no collective"},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
             "tokens_per_s": round(work.num_seqs * world / (ms_per_step * 1e-3), 1),

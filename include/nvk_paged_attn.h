@@ -43,6 +43,7 @@ extern "C" {
 
 typedef struct nvk_pool          nvk_pool;          /* device-resident paged KV pool */
 typedef struct nvk_block_manager nvk_block_manager; /* host-side block allocator     */
+typedef struct nvk_plan          nvk_plan;          /* a batch's decode work list    */
 
 const char *nvk_version(void);
 /* thread-local, never NULL; valid until the thread's next failing call */
@@ -125,22 +126,43 @@ int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, cons
                       const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
                       float *out_dev, int flags, int chunk_tokens, void *stream);
 
-/* Pre-size the split-K workspace so later nvk_decode_device calls of up to
- * this shape do not allocate. */
+/* Pre-size the split-K workspace and the pool's own plan so later
+ * nvk_decode_device calls of up to this shape do not allocate. */
 int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int chunk_tokens);
+
+/* Decode plans.  nvk_decode_device first turns the batch's context lengths
+ * into a work list on the device (one small kernel: chunks of every sequence,
+ * longest first, so ragged batches drain evenly over the CUs) and then runs
+ * it.  The list depends on the lengths only, not on the layer: an engine
+ * builds it once per model step with nvk_plan_build and runs every layer with
+ * nvk_decode_planned -- the role the reference's per-step bookkeeping
+ * (positions and block tables shared by all layers, include/core/model.hpp:157-221)
+ * plays on the CPU.  Build and use a plan on the same stream (or order the
+ * streams yourself).  nvk_plan_build may allocate; nvk_decode_planned never does.
+ * ctx_lens_dev is a device pointer.  out4 = {chunk_tokens, max_chunks,
+ * workgroup bound, kv-heads per workgroup}. */
+int nvk_plan_create(nvk_pool *pool, nvk_plan **out_plan);
+int nvk_plan_destroy(nvk_plan *plan);
+int nvk_plan_build(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_lens_dev, int max_ctx, int flags,
+                   int chunk_tokens, void *stream);
+int nvk_plan_info(const nvk_plan *plan, int *out4);
+int nvk_decode_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float *q_dev,
+                       const int *block_tables_dev, int max_blocks, float *out_dev, void *stream);
 
 /* HIP-event timing of the device form, on the pool's stream (the stream the
  * kernels are launched on): `warmup` untimed layer-calls, a stream
- * synchronise, then ONE timed region of `iters` layer-calls.
- *   total_ms  region time / iters (attention kernel + merge kernel + gaps)
+ * synchronise, then ONE timed region of `iters` layer-calls.  Call i rebuilds
+ * the plan when i % replan_every == 0 (1 = every call, exactly
+ * nvk_decode_device; L = once per L calls, as for the L layers of a model step).
+ *   total_ms  region time / iters (plan + attention + merge kernels + gaps)
  *   attn_ms   mean over the same region of the attention kernel's own
  *             duration, from an event pair around each of its launches
  * Either may be NULL; iters == 0 only warms up.  Returns after the region has
  * finished on the device. */
 int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
                      const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
-                     float *out_dev, int flags, int chunk_tokens, int warmup, int iters, float *total_ms,
-                     float *attn_ms);
+                     float *out_dev, int flags, int chunk_tokens, int replan_every, int warmup, int iters,
+                     float *total_ms, float *attn_ms);
 
 /* Drop-in for the reference function, same eleven arguments, host pointers.
  * ref: Attention::paged_attention, include/core/attention.hpp:82-92.

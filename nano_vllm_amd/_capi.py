@@ -75,8 +75,13 @@ SIGNATURES = {
     "nvk_decode_bench": (
         C.c_int,
         [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
-         _f, _f],
+         C.c_int, _f, _f],
     ),
+    "nvk_plan_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "nvk_plan_destroy": (C.c_int, [_vp]),
+    "nvk_plan_build": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "nvk_plan_info": (C.c_int, [_vp, _i]),
+    "nvk_decode_planned": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "nvk_paged_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nvk_bind_pool": (C.c_int, [_vp, C.c_int]),
     "nvk_bm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),

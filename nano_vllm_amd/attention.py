@@ -91,14 +91,48 @@ def decode_device(pool: PagedKVPool, layer: int, num_seqs: int, n_heads: int, q_
                                             _devptr(stream)))
 
 
+class DecodePlan:
+    """A batch's decode work list, reusable across the layers of one model step (``nvk_plan_*``)."""
+
+    def __init__(self, pool: PagedKVPool):
+        h = C.c_void_p()
+        _capi.check(_capi.lib.nvk_plan_create(pool.handle, C.byref(h)))
+        self._h, self.pool = h, pool
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _capi.lib.nvk_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def build(self, num_seqs: int, n_heads: int, ctx_lens_dev, max_ctx: int, flags: int = AUTO,
+              chunk_tokens: int = 0, stream=None) -> "DecodePlan":
+        _capi.check(_capi.lib.nvk_plan_build(self._h, int(num_seqs), int(n_heads), _devptr(ctx_lens_dev),
+                                             int(max_ctx), int(flags), int(chunk_tokens), _devptr(stream)))
+        return self
+
+    def info(self) -> dict:
+        out = (C.c_int * 4)()
+        _capi.check(_capi.lib.nvk_plan_info(self._h, out))
+        return {"chunk_tokens": out[0], "max_chunks": out[1], "workgroup_bound": out[2], "waves": out[3]}
+
+    def run(self, layer: int, q_dev, block_tables_dev, max_blocks: int, out_dev, stream=None) -> None:
+        _capi.check(_capi.lib.nvk_decode_planned(self.pool.handle, int(layer), self._h, _devptr(q_dev),
+                                                 _devptr(block_tables_dev), int(max_blocks), _devptr(out_dev),
+                                                 _devptr(stream)))
+
+
 def decode_bench(pool: PagedKVPool, layer: int, num_seqs: int, n_heads: int, q_dev, block_tables_dev,
                  max_blocks: int, ctx_lens_dev, max_ctx: int, out_dev, flags: int = AUTO, chunk_tokens: int = 0,
-                 warmup: int = 5, iters: int = 20, want_attn: bool = True) -> Tuple[float, Optional[float]]:
+                 warmup: int = 5, iters: int = 20, want_attn: bool = True,
+                 replan_every: int = 1) -> Tuple[float, Optional[float]]:
     """HIP-event timing on the pool's stream: (ms per layer-call, ms per attention kernel)."""
     total = C.c_float(0.0)
     attn = C.c_float(0.0)
     _capi.check(_capi.lib.nvk_decode_bench(pool.handle, int(layer), int(num_seqs), int(n_heads), _devptr(q_dev),
                                            _devptr(block_tables_dev), int(max_blocks), _devptr(ctx_lens_dev),
-                                           int(max_ctx), _devptr(out_dev), int(flags), int(chunk_tokens), int(warmup),
-                                           int(iters), C.byref(total), C.byref(attn) if want_attn else None))
+                                           int(max_ctx), _devptr(out_dev), int(flags), int(chunk_tokens),
+                                           int(replan_every), int(warmup), int(iters), C.byref(total),
+                                           C.byref(attn) if want_attn else None))
     return float(total.value), (float(attn.value) if want_attn else None)

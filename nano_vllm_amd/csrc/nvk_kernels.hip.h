@@ -7,15 +7,20 @@
 //   &K[t, kvh, 0] = key_cache + (row(t) * n_kv_heads + kvh) * head_dim
 //
 // How it is mapped to the machine:
-//   * work item = (sequence, token chunk); one workgroup per item; wave w of
-//     the workgroup owns kv-head (blockIdx.z*waves + w) and its QPK q-heads,
-//     so the waves of a workgroup together stream whole, contiguous token rows.
+//   * work item = (sequence, token chunk).  nvk_plan_kernel turns the batch's
+//     context lengths into a list of items, longest first (all full chunks,
+//     then the ragged last chunks by decreasing length), so a ragged batch
+//     drains evenly over the 256 CUs; one workgroup per item.
+//   * wave w of a workgroup owns kv-head (group*waves + w) and its QPK
+//     q-heads, so the waves of a workgroup together stream whole, contiguous
+//     token rows of the pool.
 //   * inside a wave the 64 lanes are 4 token slots x 16 lanes; a slot's 16
 //     lanes cover one (token, kv-head) row with VPL float4 each (lane r owns
 //     dims 64*j + 4*r .. +3).  One wave load instruction therefore fetches
 //     four tokens x 256 contiguous bytes = 8 full 128-B lines, every byte used.
-//   * K/V go straight from HBM to VGPRs (no reuse, so no LDS round trip), two
-//     token quads per step, double buffered: 8-16 KiB in flight per wave.
+//   * K/V go straight from HBM to VGPRs with the non-temporal hint (read once,
+//     no reuse, so no LDS round trip), kStepTokens tokens per step, double
+//     buffered: 8-16 KiB in flight per wave.
 //   * QK^T: 4*VPL FMAs per (token, q-head) then a 16-lane all-reduce done with
 //     four DPP adds (quad_perm, quad_perm, row_half_mirror, row_mirror); no
 //     LDS, no cross-row traffic in the loop.
@@ -23,7 +28,7 @@
 //     in registers, in the exp2 domain (q is pre-scaled by log2(e)/sqrt(hd)).
 //   * the chunk's slice of the block table is staged once per workgroup in LDS.
 //   * at the end the four slots are merged with two xor-shuffles, and either
-//     the normalised row is written (one chunk per sequence) or an
+//     the normalised row is written (sequence with one chunk) or an
 //     unnormalised partial (m, l, o) goes to the split-K workspace, merged by
 //     nvk_merge_kernel (flash-decoding).
 #pragma once
@@ -43,17 +48,6 @@
 #ifndef NVK_NT_LOADS
 #define NVK_NT_LOADS 1 // 1: K/V loads carry the non-temporal hint (read-once stream)
 #endif
-#ifndef NVK_SCHED_BARRIER
-#define NVK_SCHED_BARRIER 0 // 1: pin "issue next tile" ahead of "consume current tile" with sched_barrier(0)
-#endif
-#if NVK_SCHED_BARRIER
-#define NVK_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define NVK_PIN() ((void)0)
-#endif
-#ifndef NVK_FUSED_MERGE
-#define NVK_FUSED_MERGE 0 // 1: the last workgroup of a sequence merges its split-K partials in-launch (measured slower: DESIGN.md)
-#endif
 
 namespace nvk {
 
@@ -64,29 +58,37 @@ constexpr float kNegBig     = -1.0e30f; // running-max seed: finite, so exp2(m -
 // The reference seeds its max with -1e10 (attention.hpp:126); in the exp2
 // domain that floor is -1e10 * log2(e).
 constexpr float kRefMaxFloorLog2 = -1.0e10f * 1.44269504088896340736f;
+constexpr int   kPlanThreads     = 1024;
+constexpr int   kPlanBuckets     = 1024;
+
+// One unit of work for a workgroup: tokens [t0, t1) of sequence `seq`.
+// w = chunk index | (chunks of the sequence << 16).
+struct __attribute__((aligned(16))) WorkItem
+{
+    int seq, w, t0, t1;
+};
 
 struct DecodeParams
 {
-    const float *k_layer; // one layer of the pool: [num_blocks, block_size, n_kv_heads, head_dim]
-    const float *v_layer;
-    const float *q;            // [num_seqs, n_heads, head_dim]
-    const int   *block_tables; // [num_seqs, max_blocks]
-    const int   *ctx_lens;     // [num_seqs]
-    float       *out;          // [num_seqs, n_heads, head_dim]
-    float       *ws_o;         // [num_seqs, max_chunks, n_heads, head_dim]  unnormalised partial outputs
-    float       *ws_ml;        // [num_seqs, max_chunks, n_heads, 2]         (running max, running sum)
-    unsigned    *ws_arrivals;  // [num_seqs, gridDim.z] split-K arrival tickets; zero between launches
-    int          max_blocks;
-    int          num_blocks;
-    int          block_size;
-    unsigned     bs_magic; // ceil(2^32 / block_size); 0 for block_size 1 (see token_block)
-    int          n_kv_heads;
-    int          n_heads;
-    int          kv_mul; // n_heads / n_kv_heads
-    int          head_dim;
-    int          chunk_tokens; // multiple of kStepTokens
-    int          max_chunks;   // 1: the kernel writes `out` itself
-    float        q_scale;      // log2(e) / sqrt(head_dim)
+    const float    *k_layer; // one layer of the pool: [num_blocks, block_size, n_kv_heads, head_dim]
+    const float    *v_layer;
+    const float    *q;            // [num_seqs, n_heads, head_dim]
+    const int      *block_tables; // [num_seqs, max_blocks]
+    const WorkItem *items;        // [*n_items], written by nvk_plan_kernel
+    const int      *n_items;
+    float          *out;   // [num_seqs, n_heads, head_dim]
+    float          *ws_o;  // [num_seqs, max_chunks, n_heads, head_dim]  unnormalised partial outputs
+    float          *ws_ml; // [num_seqs, max_chunks, n_heads, 2]         (running max, running sum)
+    int             max_blocks;
+    int             num_blocks;
+    int             block_size;
+    unsigned        bs_magic; // ceil(2^32 / block_size); 0 for block_size 1 (see token_block)
+    int             n_kv_heads;
+    int             n_heads;
+    int             kv_mul; // n_heads / n_kv_heads
+    int             head_dim;
+    int             max_chunks;
+    float           q_scale; // log2(e) / sqrt(head_dim)
 };
 
 // ---- address arithmetic shared by decode, gather and append ---------------
@@ -152,19 +154,124 @@ __device__ __forceinline__ float4 load_kv(const float *p)
 #endif
 }
 
+// ---- the plan kernel: context lengths -> work items, longest first ----------
+// One workgroup.  Full chunks (all the same length) come first, sequence-major;
+// the ragged last chunks follow by decreasing length (counting sort on the
+// length), so the grid's tail is made of the shortest items.  A sequence with no
+// context gets one empty item: its workgroup zeroes the output row, as the
+// reference does first of all (attention.hpp:98).  Which of two equally long
+// partial chunks comes first is arbitrary and does not affect any result: every
+// item is computed independently and merged per sequence in chunk order.
+// Inclusive scan of one int per thread over the whole workgroup (kPlanThreads = 16 waves):
+// shuffle scan inside each wave, wave totals through LDS, two barriers in all.
+__device__ __forceinline__ int block_inclusive_scan(int v, int *s_wave_totals)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(v, d);
+        if (lane >= d)
+            v += up;
+    }
+    __syncthreads(); // previous readers of s_wave_totals are done
+    if (lane == 63)
+        s_wave_totals[wave] = v;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < kPlanThreads / 64; w++)
+        before += w < wave ? s_wave_totals[w] : 0;
+    return v + before;
+}
+
+__global__ void __launch_bounds__(kPlanThreads)
+    nvk_plan_kernel(const int *__restrict__ ctx_lens, int num_seqs, int chunk_tokens, int max_chunks,
+                    WorkItem *__restrict__ items, int *__restrict__ n_items, int *__restrict__ seq_chunks)
+{
+    static_assert(kPlanBuckets == kPlanThreads, "one bucket per thread in the bucket scan");
+    __shared__ int s_totals[kPlanThreads / 64];
+    __shared__ int s_hist[kPlanBuckets];
+    __shared__ int s_start[kPlanBuckets];
+
+    const int tid = threadIdx.x;
+    s_hist[tid]   = 0;
+    __syncthreads();
+
+    auto bucket_of = [&](int rem) { // rem in [0, chunk_tokens): longer remainders get higher buckets
+        return (int)(((int64_t)rem * kPlanBuckets) / chunk_tokens);
+    };
+    const int ctx_cap = max_chunks * chunk_tokens;
+
+    // pass 1: full chunks, sequence-major; histogram of the ragged remainders
+    int n_full = 0;
+    for (int base = 0; base < num_seqs; base += kPlanThreads) {
+        const int s     = base + tid;
+        const int ctx   = s < num_seqs ? min(max(ctx_lens[s], 0), ctx_cap) : 0;
+        const int nfull = ctx / chunk_tokens;
+        const int rem   = ctx - nfull * chunk_tokens;
+        const int nch   = nfull + (rem > 0 ? 1 : 0);
+        const int incl  = block_inclusive_scan(nfull, s_totals);
+        const int first = n_full + incl - nfull;
+        for (int c = 0; c < nfull; c++)
+            items[first + c] = WorkItem{s, c | (nch << 16), c * chunk_tokens, (c + 1) * chunk_tokens};
+        if (s < num_seqs) {
+            seq_chunks[s] = nch;
+            if (rem > 0 || ctx == 0)
+                atomicAdd(&s_hist[bucket_of(rem)], 1);
+        }
+#pragma unroll
+        for (int w = 0; w < kPlanThreads / 64; w++)
+            n_full += s_totals[w]; // every thread keeps the running total itself
+    }
+    __syncthreads(); // histogram complete
+
+    // descending exclusive scan over the buckets: s_start[b] = items in buckets above b
+    const int b_mine = kPlanBuckets - 1 - tid;
+    const int h_mine = s_hist[b_mine];
+    const int incl   = block_inclusive_scan(h_mine, s_totals);
+    s_start[b_mine]  = incl - h_mine;
+    int n_part       = 0;
+#pragma unroll
+    for (int w = 0; w < kPlanThreads / 64; w++)
+        n_part += s_totals[w];
+    __syncthreads(); // everyone has read its s_hist entry
+    s_hist[tid] = 0; // reused as per-bucket cursors
+    __syncthreads();
+
+    // pass 2: scatter the ragged last chunks (and the empty sequences) behind the full ones
+    for (int s = tid; s < num_seqs; s += kPlanThreads) {
+        const int ctx   = min(max(ctx_lens[s], 0), ctx_cap);
+        const int nfull = ctx / chunk_tokens;
+        const int rem   = ctx - nfull * chunk_tokens;
+        if (rem > 0 || ctx == 0) {
+            const int b   = bucket_of(rem);
+            const int pos = s_start[b] + atomicAdd(&s_hist[b], 1);
+            const int nch = nfull + (rem > 0 ? 1 : 0);
+            items[n_full + pos] = WorkItem{s, nfull | (nch << 16), nfull * chunk_tokens, ctx};
+        }
+    }
+    if (tid == 0)
+        *n_items = n_full + n_part;
+}
+
 // ---- the decode kernel ----------------------------------------------------
 // VPL   float4 per lane per row (head_dim <= 64*VPL)
-// QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.z also walks kv_mul/QPK)
+// QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.y also walks kv_mul/QPK)
 // FULL  head_dim == 64*VPL, so no lane is idle and no load needs a predicate
+// grid: x = work item (upper bound; workgroups past *n_items leave), y = kv-head group x q sub-group
 template <int VPL, int QPK, bool FULL>
 __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(const DecodeParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice
 
-    const int seq   = blockIdx.y;
-    const int chunk = blockIdx.x;
-    const int ctx   = p.ctx_lens[seq];
-    const int t0    = chunk * p.chunk_tokens;
+    if ((int)blockIdx.x >= *p.n_items)
+        return;
+    const WorkItem item  = p.items[blockIdx.x];
+    const int      seq   = item.seq;
+    const int      chunk = item.w & 0xFFFF;
+    const int      nch   = item.w >> 16; // chunks of this sequence: 1 -> this workgroup writes `out` itself
+    const int      t0    = item.t0;
+    const int      t1    = item.t1;
 
     const int lane   = threadIdx.x & 63;
     const int wave   = threadIdx.x >> 6;
@@ -172,12 +279,12 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
     const int slot   = lane >> 4; // which token of a quad
     const int r      = lane & 15; // which 16 B of a 256-B row piece
 
-    // blockIdx.z enumerates (kv-head group, q sub-group); waves enumerate kv-heads in the group
-    const int qsplit = p.kv_mul / QPK;
-    const int zq     = blockIdx.z % qsplit;
-    const int kvh    = (blockIdx.z / qsplit) * nwaves + wave;
-    const bool live  = kvh < p.n_kv_heads;
-    const int  qh0   = kvh * p.kv_mul + zq * QPK; // first q-head of this wave
+    // blockIdx.y enumerates (kv-head group, q sub-group); waves enumerate kv-heads in the group
+    const int  qsplit = p.kv_mul / QPK;
+    const int  zq     = blockIdx.y % qsplit;
+    const int  kvh    = (blockIdx.y / qsplit) * nwaves + wave;
+    const bool live   = kvh < p.n_kv_heads;
+    const int  qh0    = kvh * p.kv_mul + zq * QPK; // first q-head of this wave
 
     const int hd = p.head_dim;
     bool      act[VPL];
@@ -185,9 +292,9 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
     for (int j = 0; j < VPL; j++)
         act[j] = FULL || (64 * j + 4 * r < hd);
 
-    if (ctx <= 0) {
-        // the reference zeroes `out` before anything else (attention.hpp:98)
-        if ((p.max_chunks == 1 || NVK_FUSED_MERGE) && chunk == 0 && live && slot == 0) {
+    if (t1 <= t0) {
+        // a sequence with no context: the reference zeroes `out` and does nothing else (attention.hpp:98)
+        if (live && slot == 0) {
 #pragma unroll
             for (int h = 0; h < QPK; h++)
 #pragma unroll
@@ -198,19 +305,34 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         }
         return;
     }
-    if (t0 >= ctx)
-        return; // whole workgroup: this sequence has fewer chunks than the grid is wide
 
-    const int t1   = min(t0 + p.chunk_tokens, ctx);
+    // q for this wave's q-heads: issued before the table staging so both latencies overlap
+    float4 qv[QPK][VPL];
+#pragma unroll
+    for (int h = 0; h < QPK; h++)
+#pragma unroll
+        for (int j = 0; j < VPL; j++) {
+            qv[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && act[j])
+                qv[h][j] = *reinterpret_cast<const float4 *>(p.q + ((int64_t)seq * p.n_heads + qh0 + h) * hd
+                                                             + 64 * j + 4 * r);
+        }
+
     const int blk0 = token_block(t0, p.bs_magic);
     const int blk1 = token_block(t1 - 1, p.bs_magic);
     for (int i = threadIdx.x; i <= blk1 - blk0; i += blockDim.x)
         s_tab[i] = clamp_block(p.block_tables[(int64_t)seq * p.max_blocks + blk0 + i], p.num_blocks);
     __syncthreads();
-#if !NVK_FUSED_MERGE
     if (!live)
         return; // no barrier after this point
-#endif
+
+    // pre-scale q into the exp2 domain
+#pragma unroll
+    for (int h = 0; h < QPK; h++)
+#pragma unroll
+        for (int j = 0; j < VPL; j++) {
+            qv[h][j].x *= p.q_scale, qv[h][j].y *= p.q_scale, qv[h][j].z *= p.q_scale, qv[h][j].w *= p.q_scale;
+        }
 
     float  m[QPK], l[QPK];
     float4 o[QPK][VPL];
@@ -222,21 +344,6 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         for (int j = 0; j < VPL; j++)
             o[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-
-    if (live) { // ---- stream this wave's kv-head over the chunk (wave-uniform branch) ----
-
-    // q for this wave's q-heads, pre-scaled into the exp2 domain
-    float4 qv[QPK][VPL];
-#pragma unroll
-    for (int h = 0; h < QPK; h++)
-#pragma unroll
-        for (int j = 0; j < VPL; j++) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act[j])
-                t = *reinterpret_cast<const float4 *>(p.q + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j
-                                                      + 4 * r);
-            qv[h][j] = make_float4(t.x * p.q_scale, t.y * p.q_scale, t.z * p.q_scale, t.w * p.q_scale);
-        }
 
     const int lane_col = kvh * hd + 4 * r; // float offset of this lane inside a token row
     const int row_len  = p.n_kv_heads * hd;
@@ -322,7 +429,7 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
     // Software pipeline over steps of kStepTokens tokens: two named tiles, hand-unrolled by two
     // (no register copies, no runtime-indexed arrays).  The steady-state loop prefetches
     // unconditionally, so every path into a consume has the same number of loads in flight and
-    // hipcc can emit counted vmcnt waits that leave the whole next tile outstanding; the last one
+    // hipcc emits counted vmcnt waits that leave the whole next tile outstanding; the last one
     // or two steps (the only ones that can run past the chunk's end) are peeled off.
     const std::integral_constant<bool, false> body;
     const std::integral_constant<bool, true>  tail;
@@ -332,15 +439,12 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
     load_tile(ta, t0);
     for (; k + 2 < nsteps; k += 2) {
         load_tile(tb, t0 + (k + 1) * kStepTokens);
-        NVK_PIN(); // issue the whole next tile before any wait on the current one
         consume_tile(ta, t0 + k * kStepTokens, body);
         load_tile(ta, t0 + (k + 2) * kStepTokens);
-        NVK_PIN();
         consume_tile(tb, t0 + (k + 1) * kStepTokens, body);
     }
     if (nsteps - k == 2) {
         load_tile(tb, t0 + (k + 1) * kStepTokens);
-        NVK_PIN();
         consume_tile(ta, t0 + k * kStepTokens, body);
         consume_tile(tb, t0 + (k + 1) * kStepTokens, tail);
     }
@@ -371,119 +475,52 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         }
     }
 
-    } // live
-
-    // How many chunks this sequence really has decides where the result goes.
-    const int  nch    = (ctx + p.chunk_tokens - 1) / p.chunk_tokens;
-    const bool direct = p.max_chunks == 1 || (NVK_FUSED_MERGE && nch == 1);
-
-    if (direct) {
-        if (live && slot == 0) {
-#pragma unroll
-            for (int h = 0; h < QPK; h++) {
-                // reference: max_val = max(-1e10, scores) (attention.hpp:126-130); a no-op unless every score is below it
-                const float mf  = fmaxf(m[h], kRefMaxFloorLog2);
-                const float f   = fast_exp2(m[h] - mf);
-                const float inv = f / (l[h] * f);
-#pragma unroll
-                for (int j = 0; j < VPL; j++)
-                    if (act[j])
-                        *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j
-                                                    + 4 * r) =
-                            make_float4(o[h][j].x * inv, o[h][j].y * inv, o[h][j].z * inv, o[h][j].w * inv);
-            }
-        }
+    if (slot != 0)
         return;
-    }
 
-    if (live && slot == 0) {
-        const int64_t item = (int64_t)seq * p.max_chunks + chunk;
+    if (nch == 1) {
+#pragma unroll
+        for (int h = 0; h < QPK; h++) {
+            // reference: max_val = max(-1e10, scores) (attention.hpp:126-130); a no-op unless every score is below it
+            const float mf  = fmaxf(m[h], kRefMaxFloorLog2);
+            const float f   = fast_exp2(m[h] - mf);
+            const float inv = f / (l[h] * f);
+#pragma unroll
+            for (int j = 0; j < VPL; j++)
+                if (act[j])
+                    *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
+                        make_float4(o[h][j].x * inv, o[h][j].y * inv, o[h][j].z * inv, o[h][j].w * inv);
+        }
+    }
+    else {
+        const int64_t slab = (int64_t)seq * p.max_chunks + chunk;
 #pragma unroll
         for (int h = 0; h < QPK; h++) {
 #pragma unroll
             for (int j = 0; j < VPL; j++)
                 if (act[j])
-                    *reinterpret_cast<float4 *>(p.ws_o + (item * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
+                    *reinterpret_cast<float4 *>(p.ws_o + (slab * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
                         o[h][j];
             if (r == 0)
-                *reinterpret_cast<float2 *>(p.ws_ml + (item * p.n_heads + qh0 + h) * 2) = make_float2(m[h], l[h]);
+                *reinterpret_cast<float2 *>(p.ws_ml + (slab * p.n_heads + qh0 + h) * 2) = make_float2(m[h], l[h]);
         }
     }
-
-#if NVK_FUSED_MERGE
-    // ---- in-launch split-K combine (cdna_hip_programming.md section 5 "In-launch split-K reduction") ----
-    // Publish: every storing wave drains its stores, the workgroup meets, ONE lane does an
-    // agent-scope release and draws a ticket.  The workgroup that draws the sequence's last
-    // ticket acquires (agent scope, one lane), the workgroup meets again, and all its waves
-    // merge every chunk's partial, in chunk order, so the result does not depend on which
-    // workgroup happens to be last.  Placement (XCD, CU, dispatch order) plays no part.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads(); // also: nobody reads s_tab[] any more, so word 0 can carry the verdict
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned *ticket = p.ws_arrivals + (int64_t)seq * gridDim.z + blockIdx.z;
-        const unsigned drawn =
-            __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = drawn == (unsigned)(nch - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // leave the ticket word zero for the next launch (a kernel boundary orders this store)
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_tab[0] = last;
-    }
-    __syncthreads();
-    if (!s_tab[0])
-        return;
-
-    // one work item = (wave's kv-head, q-head of it, float4 of head_dim); same maths as nvk_merge_kernel
-    const int vec_row = hd >> 2;
-    const int items   = nwaves * QPK * vec_row;
-    for (int it = threadIdx.x; it < items; it += blockDim.x) {
-        const int w   = it / (QPK * vec_row);
-        const int rem = it - w * (QPK * vec_row);
-        const int h   = rem / vec_row;
-        const int vec = rem - h * vec_row;
-        const int kv2 = (blockIdx.z / qsplit) * nwaves + w;
-        if (kv2 >= p.n_kv_heads)
-            continue;
-        const int    head = kv2 * p.kv_mul + zq * QPK + h;
-        const float *ml   = p.ws_ml + ((int64_t)seq * p.max_chunks * p.n_heads + head) * 2;
-        const float *po   = p.ws_o + ((int64_t)seq * p.max_chunks * p.n_heads + head) * hd + 4 * vec;
-        float        top  = kRefMaxFloorLog2;
-        for (int c = 0; c < nch; c++)
-            top = fmaxf(top, ml[(int64_t)c * p.n_heads * 2]);
-        float  denom = 0.f;
-        float4 acc   = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = 0; c < nch; c++) {
-            const float2 sc = *reinterpret_cast<const float2 *>(ml + (int64_t)c * p.n_heads * 2);
-            const float  f  = fast_exp2(sc.x - top);
-            const float4 a  = *reinterpret_cast<const float4 *>(po + (int64_t)c * p.n_heads * hd);
-            denom           = fmaf(sc.y, f, denom);
-            acc.x           = fmaf(a.x, f, acc.x);
-            acc.y           = fmaf(a.y, f, acc.y);
-            acc.z           = fmaf(a.z, f, acc.z);
-            acc.w           = fmaf(a.w, f, acc.w);
-        }
-        const float inv = 1.0f / denom;
-        *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + head) * hd + 4 * vec) =
-            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-    }
-#endif
 }
 
 // ---- split-K merge (flash-decoding combine) ---------------------------------
 // One thread per (sequence, q-head, float4 of head_dim): log-sum-exp merge of
-// the sequence's chunk partials, then the reference's normalisation.
+// the sequence's chunk partials, in chunk order, then the reference's
+// normalisation.  Sequences with at most one chunk were finished by
+// nvk_decode_kernel and are skipped.
 __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict__ ws_o,
                                                         const float *__restrict__ ws_ml,
-                                                        const int *__restrict__ ctx_lens, float *__restrict__ out,
-                                                        int n_heads, int head_dim, int chunk_tokens,
-                                                        int max_chunks)
+                                                        const int *__restrict__ seq_chunks, float *__restrict__ out,
+                                                        int n_heads, int head_dim, int max_chunks)
 {
-    const int seq     = blockIdx.y;
+    const int seq = blockIdx.y;
+    const int nch = min(seq_chunks[seq], max_chunks);
+    if (nch <= 1)
+        return;
     const int vec_row = head_dim >> 2; // float4 per head
     const int idx     = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_heads * vec_row)
@@ -491,22 +528,14 @@ __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict_
     const int head = idx / vec_row;
     const int vec  = idx - head * vec_row;
 
-    const int ctx = ctx_lens[seq];
-    const int nch = ctx <= 0 ? 0 : min((ctx + chunk_tokens - 1) / chunk_tokens, max_chunks);
-
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float *dst = out + ((int64_t)seq * n_heads + head) * head_dim + 4 * vec;
-    if (nch == 0) {
-        *reinterpret_cast<float4 *>(dst) = acc;
-        return;
-    }
     const float *ml = ws_ml + ((int64_t)seq * max_chunks * n_heads + head) * 2;
     const float *po = ws_o + ((int64_t)seq * max_chunks * n_heads + head) * head_dim + 4 * vec;
 
     float top = kRefMaxFloorLog2; // the reference's -1e10 floor, see nvk_decode_kernel
     for (int c = 0; c < nch; c++)
         top = fmaxf(top, ml[(int64_t)c * n_heads * 2]);
-    float denom = 0.f;
+    float  denom = 0.f;
+    float4 acc   = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < nch; c++) {
         const float2 s = *reinterpret_cast<const float2 *>(ml + (int64_t)c * n_heads * 2);
         const float  f = fast_exp2(s.x - top);
@@ -517,8 +546,9 @@ __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict_
         acc.z          = fmaf(a.z, f, acc.z);
         acc.w          = fmaf(a.w, f, acc.w);
     }
-    const float inv                  = 1.0f / denom;
-    *reinterpret_cast<float4 *>(dst) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    const float inv = 1.0f / denom;
+    *reinterpret_cast<float4 *>(out + ((int64_t)seq * n_heads + head) * head_dim + 4 * vec) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
 // ---- KV gather on its own (addressing check) --------------------------------

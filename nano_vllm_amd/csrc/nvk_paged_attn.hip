@@ -21,6 +21,9 @@
 #ifndef NVK_WG_WAVES
 #define NVK_WG_WAVES 8 // kv-heads (= waves) per workgroup, at most
 #endif
+#ifndef NVK_AUTO_MAX_CHUNK
+#define NVK_AUTO_MAX_CHUNK 2048 // longest chunk NVK_DECODE_AUTO picks
+#endif
 
 // ------------------------------------------------------------------ errors
 namespace nvk {
@@ -89,9 +92,12 @@ struct nvk_pool
     int         num_cus = 256;
 
     // split-K workspace (grown on demand, reused across calls)
-    float    *ws_o = nullptr, *ws_ml = nullptr;
-    unsigned *ws_arrivals = nullptr; // split-K tickets; every launch leaves them zero again
-    size_t    ws_o_floats = 0, ws_ml_floats = 0, ws_arrival_words = 0;
+    float *ws_o = nullptr, *ws_ml = nullptr;
+    size_t ws_o_floats = 0, ws_ml_floats = 0;
+
+    // the plan nvk_decode / nvk_decode_device rebuild on every call (callers that
+    // reuse one plan across the layers of a model step own an nvk_plan instead)
+    nvk_plan *own_plan = nullptr;
 
     // staging for the host-pointer entry points
     char  *stage     = nullptr;
@@ -122,20 +128,8 @@ int ensure_stage(nvk_pool *pool, size_t bytes)
     return NVK_OK;
 }
 
-int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats, size_t arrival_words)
+int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
 {
-    if (arrival_words > pool->ws_arrival_words) {
-        if (pool->ws_arrivals) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(pool->ws_arrivals));
-            pool->ws_arrivals      = nullptr;
-            pool->ws_arrival_words = 0;
-        }
-        const size_t words = (arrival_words + 63) / 64 * 64;
-        HIP_TRY(hipMalloc(&pool->ws_arrivals, words * sizeof(unsigned)));
-        HIP_TRY(hipMemset(pool->ws_arrivals, 0, words * sizeof(unsigned))); // synchronous: ordered before any stream's launch
-        pool->ws_arrival_words = words;
-    }
     if (o_floats > pool->ws_o_floats) {
         if (pool->ws_o) {
             HIP_TRY(hipDeviceSynchronize());
@@ -169,7 +163,7 @@ int check_pool_layer(const nvk_pool *pool, int layer, const char *who)
 }
 
 // ------------------------------------------------------------ launch plan
-struct LaunchPlan
+struct LaunchShape
 {
     int chunk_tokens = 0; // multiple of kStepTokens
     int max_chunks   = 1;
@@ -183,8 +177,8 @@ struct LaunchPlan
 
 constexpr int kMaxTableSliceEntries = 8192; // 32 KiB of LDS per workgroup at most
 
-int make_plan(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens,
-              LaunchPlan *plan)
+int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens,
+               LaunchShape *plan)
 {
     const int hd = pool->head_dim;
     if (n_heads <= 0 || n_heads % pool->n_kv_heads != 0)
@@ -214,20 +208,25 @@ int make_plan(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int 
         chunk = round_up(chunk_tokens, step);
     }
     else {
-        // AUTO (and SPLIT_K with no size).  Measured on config 2 (profiles/): a workgroup should
-        // stream as long a chunk as possible while the grid still covers every CU about once
-        // (8 waves at 192 VGPRs = one workgroup per CU); 1024 tokens caps the imbalance a
-        // ragged batch can suffer, 128 keeps the per-chunk prologue/epilogue small.
+        // AUTO (and SPLIT_K with no size).  Measured (profiles/r01_*): a workgroup should stream as
+        // long a chunk as it can while the grid still covers every CU about once (8 waves at
+        // 168-192 VGPRs = one workgroup per CU); with the longest-first item order a ragged
+        // batch tolerates chunks up to 2048 tokens; 128 keeps the prologue/epilogue share small.
         const long long wg_per_chunk = std::max<long long>(1, (long long)plan->kv_groups * (kv_mul / plan->qpk));
         const long long tokens_upper = (long long)num_seqs * ctx_cap * wg_per_chunk;
         chunk = round_up((int)std::min<long long>(1 << 20, (tokens_upper + pool->num_cus - 1) / pool->num_cus), 128);
-        chunk = std::max<long long>(128, std::min<long long>(chunk, 1024));
+        chunk = std::max<long long>(128, std::min<long long>(chunk, NVK_AUTO_MAX_CHUNK));
     }
     chunk = std::min<long long>(chunk, ctx_cap);
     chunk = std::min<long long>(chunk, slice_cap);
     chunk = std::max<long long>(chunk, step);
     plan->chunk_tokens = (int)chunk;
     plan->max_chunks   = (ctx_cap + plan->chunk_tokens - 1) / plan->chunk_tokens;
+    if (plan->max_chunks > 32767)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "chunk_tokens=%d splits max_ctx=%d into more than 32767 chunks",
+                         plan->chunk_tokens, max_ctx);
+    if ((unsigned long long)max_ctx * (unsigned)pool->block_size >= (1ULL << 32))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "max_ctx=%d too long for block_size=%d", max_ctx, pool->block_size);
     plan->lds_bytes    = ((size_t)plan->chunk_tokens / pool->block_size + 2) * sizeof(int);
     return NVK_OK;
 }
@@ -256,7 +255,7 @@ template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, d
     }
 }
 
-hipError_t launch_decode(const LaunchPlan &plan, dim3 grid, dim3 block, hipStream_t stream, const nvk::DecodeParams &p)
+hipError_t launch_decode(const LaunchShape &plan, dim3 grid, dim3 block, hipStream_t stream, const nvk::DecodeParams &p)
 {
     switch (plan.vpl) {
     case 1: return launch_decode_qpk<1>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
@@ -265,43 +264,117 @@ hipError_t launch_decode(const LaunchPlan &plan, dim3 grid, dim3 block, hipStrea
     }
 }
 
-// Enqueue one layer-call on `stream`.  All pointers are device pointers.
-// ev_mid_a/ev_mid_b (optional) bracket the attention kernel alone.
-int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev, const int *tables_dev,
-                   int max_blocks, const int *ctx_dev, int max_ctx, float *out_dev, int flags, int chunk_tokens,
-                   hipStream_t stream, hipEvent_t ev_attn_begin, hipEvent_t ev_attn_end)
+} // namespace
+
+// A decode plan: the batch's work items (built on the device from its context
+// lengths) plus the launch shape.  Depends on the lengths only, so one plan
+// serves every layer of a model step.
+struct nvk_plan
 {
-    if (num_seqs == 0)
-        return NVK_OK;
-    LaunchPlan plan;
-    int        rc = make_plan(pool, num_seqs, n_heads, max_ctx, flags, chunk_tokens, &plan);
+    nvk_pool     *pool = nullptr;
+    int           num_seqs = 0, n_heads = 0, max_ctx = 0;
+    LaunchShape   shape;
+    bool          built = false;
+    nvk::WorkItem *items = nullptr;
+    int          *counters = nullptr; // [0] = n_items, [1 + s] = chunks of sequence s
+    size_t        cap_items = 0, cap_seqs = 0;
+    int           item_bound = 0; // grid.x: at least as many workgroups as items
+};
+
+namespace {
+
+int plan_reserve(nvk_plan *plan, size_t items, size_t seqs)
+{
+    if (items > plan->cap_items) {
+        if (plan->items) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(plan->items));
+            plan->items     = nullptr;
+            plan->cap_items = 0;
+        }
+        const size_t want = std::max(items, (size_t)1024);
+        HIP_TRY(hipMalloc(&plan->items, want * sizeof(nvk::WorkItem)));
+        plan->cap_items = want;
+    }
+    if (seqs > plan->cap_seqs) {
+        if (plan->counters) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(plan->counters));
+            plan->counters = nullptr;
+            plan->cap_seqs = 0;
+        }
+        const size_t want = std::max(seqs, (size_t)1024);
+        HIP_TRY(hipMalloc(&plan->counters, (want + 1) * sizeof(int)));
+        plan->cap_seqs = want;
+    }
+    return NVK_OK;
+}
+
+// Builds `plan` for a batch on `stream` (one small kernel).  ctx_dev is a device pointer.
+int build_plan(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, int max_ctx, int flags, int chunk_tokens,
+               hipStream_t stream)
+{
+    nvk_pool *pool = plan->pool;
+    plan->built    = false;
+    int rc         = make_shape(pool, num_seqs, n_heads, max_ctx, flags, chunk_tokens, &plan->shape);
     if (rc != NVK_OK)
         return rc;
-    if ((long long)max_blocks * pool->block_size < max_ctx)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "max_blocks=%d x block_size=%d cannot hold max_ctx=%d", max_blocks,
-                         pool->block_size, max_ctx);
-    if (num_seqs > 65535 * 1)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "num_seqs=%d exceeds the grid's y extent (65535)", num_seqs);
-
-    const int kv_mul = n_heads / pool->n_kv_heads;
-    const unsigned grid_z = (unsigned)(plan.kv_groups * (kv_mul / plan.qpk));
-    if (plan.max_chunks > 1) {
-        rc = ensure_workspace(pool, (size_t)num_seqs * plan.max_chunks * n_heads * pool->head_dim,
-                              (size_t)num_seqs * plan.max_chunks * n_heads * 2, (size_t)num_seqs * grid_z);
+    const LaunchShape &sh = plan->shape;
+    if ((long long)num_seqs * sh.max_chunks > 0x7fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "num_seqs=%d x %d chunks exceeds the grid", num_seqs, sh.max_chunks);
+    plan->num_seqs = num_seqs, plan->n_heads = n_heads, plan->max_ctx = max_ctx;
+    plan->item_bound = num_seqs * sh.max_chunks;
+    if (num_seqs == 0) {
+        plan->built = true;
+        return NVK_OK;
+    }
+    rc = plan_reserve(plan, (size_t)plan->item_bound, (size_t)num_seqs);
+    if (rc != NVK_OK)
+        return rc;
+    if (sh.max_chunks > 1) {
+        rc = ensure_workspace(pool, (size_t)num_seqs * sh.max_chunks * n_heads * pool->head_dim,
+                              (size_t)num_seqs * sh.max_chunks * n_heads * 2);
         if (rc != NVK_OK)
             return rc;
     }
+    hipLaunchKernelGGL(nvk::nvk_plan_kernel, dim3(1), dim3(nvk::kPlanThreads), 0, stream, ctx_dev, num_seqs,
+                       sh.chunk_tokens, sh.max_chunks, plan->items, plan->counters, plan->counters + 1);
+    HIP_TRY(hipGetLastError());
+    plan->built = true;
+    return NVK_OK;
+}
+
+// Enqueue one layer-call of a built plan on `stream`.  All pointers are device pointers.
+// ev_attn_begin/ev_attn_end (optional) bracket the attention kernel alone.
+int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float *q_dev, const int *tables_dev,
+                    int max_blocks, float *out_dev, hipStream_t stream, hipEvent_t ev_attn_begin,
+                    hipEvent_t ev_attn_end)
+{
+    if (!plan->built || plan->pool != pool)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "decode: the plan was not built for this pool");
+    if (plan->num_seqs == 0)
+        return NVK_OK;
+    const LaunchShape &sh = plan->shape;
+    if ((long long)max_blocks * pool->block_size < plan->max_ctx)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "max_blocks=%d x block_size=%d cannot hold max_ctx=%d", max_blocks,
+                         pool->block_size, plan->max_ctx);
+    const int n_heads = plan->n_heads;
+    const int kv_mul  = n_heads / pool->n_kv_heads;
+    if (sh.max_chunks > 1
+        && (pool->ws_o_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * pool->head_dim
+            || pool->ws_ml_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * 2))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "decode: split-K workspace smaller than the plan needs");
 
     nvk::DecodeParams p;
     p.k_layer      = pool->k_layer(layer);
     p.v_layer      = pool->v_layer(layer);
     p.q            = q_dev;
     p.block_tables = tables_dev;
-    p.ctx_lens     = ctx_dev;
+    p.items        = plan->items;
+    p.n_items      = plan->counters;
     p.out          = out_dev;
     p.ws_o         = pool->ws_o;
     p.ws_ml        = pool->ws_ml;
-    p.ws_arrivals  = pool->ws_arrivals;
     p.max_blocks   = max_blocks;
     p.num_blocks   = pool->num_blocks;
     p.block_size   = pool->block_size;
@@ -310,26 +383,65 @@ int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const f
     p.n_heads      = n_heads;
     p.kv_mul       = kv_mul;
     p.head_dim     = pool->head_dim;
-    p.chunk_tokens = plan.chunk_tokens;
-    p.max_chunks   = plan.max_chunks;
+    p.max_chunks   = sh.max_chunks;
     p.q_scale      = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
 
-    const dim3 grid((unsigned)plan.max_chunks, (unsigned)num_seqs, grid_z);
-    const dim3 block((unsigned)plan.waves * 64);
+    const dim3 grid((unsigned)plan->item_bound, (unsigned)(sh.kv_groups * (kv_mul / sh.qpk)));
+    const dim3 block((unsigned)sh.waves * 64);
     if (ev_attn_begin)
         HIP_TRY(hipEventRecord(ev_attn_begin, stream));
-    HIP_TRY(launch_decode(plan, grid, block, stream, p));
+    HIP_TRY(launch_decode(sh, grid, block, stream, p));
     if (ev_attn_end)
         HIP_TRY(hipEventRecord(ev_attn_end, stream));
 
-    if (plan.max_chunks > 1 && !NVK_FUSED_MERGE) {
+    if (sh.max_chunks > 1) {
         const int  vecs = n_heads * (pool->head_dim / 4);
-        const dim3 mgrid((unsigned)((vecs + 255) / 256), (unsigned)num_seqs);
-        hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml, ctx_dev, out_dev,
-                           n_heads, pool->head_dim, plan.chunk_tokens, plan.max_chunks);
+        const dim3 mgrid((unsigned)((vecs + 255) / 256), (unsigned)plan->num_seqs);
+        hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
+                           plan->counters + 1, out_dev, n_heads, pool->head_dim, sh.max_chunks);
         HIP_TRY(hipGetLastError());
     }
     return NVK_OK;
+}
+
+int own_plan_of(nvk_pool *pool, nvk_plan **out)
+{
+    if (!pool->own_plan) {
+        pool->own_plan = new (std::nothrow) nvk_plan();
+        if (!pool->own_plan)
+            return nvk::fail(NVK_ERR_OOM, "host allocation failed");
+        pool->own_plan->pool = pool;
+    }
+    *out = pool->own_plan;
+    return NVK_OK;
+}
+
+void free_plan(nvk_plan *plan)
+{
+    if (!plan)
+        return;
+    if (plan->items)
+        (void)hipFree(plan->items);
+    if (plan->counters)
+        (void)hipFree(plan->counters);
+    delete plan;
+}
+
+// plan + run, the shape of nvk_decode_device
+int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev, const int *tables_dev,
+                   int max_blocks, const int *ctx_dev, int max_ctx, float *out_dev, int flags, int chunk_tokens,
+                   hipStream_t stream)
+{
+    if (num_seqs == 0)
+        return NVK_OK;
+    nvk_plan *plan = nullptr;
+    int       rc   = own_plan_of(pool, &plan);
+    if (rc != NVK_OK)
+        return rc;
+    rc = build_plan(plan, num_seqs, n_heads, ctx_dev, max_ctx, flags, chunk_tokens, stream);
+    if (rc != NVK_OK)
+        return rc;
+    return enqueue_planned(pool, layer, plan, q_dev, tables_dev, max_blocks, out_dev, stream, nullptr, nullptr);
 }
 
 // thread-local binding for the drop-in entry point
@@ -432,8 +544,7 @@ int nvk_pool_destroy(nvk_pool *pool)
         (void)hipFree(pool->ws_o);
     if (pool->ws_ml)
         (void)hipFree(pool->ws_ml);
-    if (pool->ws_arrivals)
-        (void)hipFree(pool->ws_arrivals);
+    free_plan(pool->own_plan);
     if (pool->stage)
         (void)hipFree(pool->stage);
     if (pool->ev_a)
@@ -662,15 +773,76 @@ int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int ma
     if (!pool || num_seqs < 0 || max_ctx < 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_reserve_workspace: bad arguments");
     DeviceScope scope(pool->device);
-    LaunchPlan  plan;
-    int rc = make_plan(pool, num_seqs, n_heads, max_ctx, chunk_tokens > 0 ? NVK_DECODE_SPLIT_K : NVK_DECODE_AUTO,
-                       chunk_tokens, &plan);
+    LaunchShape shape;
+    int rc = make_shape(pool, num_seqs, n_heads, max_ctx, chunk_tokens > 0 ? NVK_DECODE_SPLIT_K : NVK_DECODE_AUTO,
+                        chunk_tokens, &shape);
     if (rc != NVK_OK)
         return rc;
-    const int kv_mul = n_heads / pool->n_kv_heads;
-    return ensure_workspace(pool, (size_t)num_seqs * plan.max_chunks * n_heads * pool->head_dim,
-                            (size_t)num_seqs * plan.max_chunks * n_heads * 2,
-                            (size_t)num_seqs * plan.kv_groups * (kv_mul / plan.qpk));
+    nvk_plan *plan = nullptr;
+    rc             = own_plan_of(pool, &plan);
+    if (rc != NVK_OK)
+        return rc;
+    rc = plan_reserve(plan, (size_t)num_seqs * shape.max_chunks, (size_t)num_seqs);
+    if (rc != NVK_OK)
+        return rc;
+    return ensure_workspace(pool, (size_t)num_seqs * shape.max_chunks * n_heads * pool->head_dim,
+                            (size_t)num_seqs * shape.max_chunks * n_heads * 2);
+}
+
+int nvk_plan_create(nvk_pool *pool, nvk_plan **out_plan)
+{
+    if (!pool || !out_plan)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_create: null argument");
+    nvk_plan *plan = new (std::nothrow) nvk_plan();
+    if (!plan)
+        return nvk::fail(NVK_ERR_OOM, "nvk_plan_create: host allocation failed");
+    plan->pool = pool;
+    *out_plan  = plan;
+    return NVK_OK;
+}
+
+int nvk_plan_destroy(nvk_plan *plan)
+{
+    if (!plan)
+        return NVK_OK;
+    DeviceScope scope(plan->pool->device);
+    (void)hipDeviceSynchronize();
+    free_plan(plan);
+    return NVK_OK;
+}
+
+int nvk_plan_build(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_lens_dev, int max_ctx, int flags,
+                   int chunk_tokens, void *stream)
+{
+    if (!plan || num_seqs < 0 || max_ctx < 0 || (num_seqs > 0 && !ctx_lens_dev))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: bad arguments");
+    if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: flags %d", flags);
+    DeviceScope scope(plan->pool->device);
+    return build_plan(plan, num_seqs, n_heads, ctx_lens_dev, max_ctx, flags, chunk_tokens,
+                      stream ? (hipStream_t)stream : plan->pool->stream);
+}
+
+int nvk_plan_info(const nvk_plan *plan, int *out4)
+{
+    if (!plan || !out4 || !plan->built)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_info: null or unbuilt plan");
+    out4[0] = plan->shape.chunk_tokens, out4[1] = plan->shape.max_chunks, out4[2] = plan->item_bound;
+    out4[3] = plan->shape.waves;
+    return NVK_OK;
+}
+
+int nvk_decode_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float *q_dev, const int *block_tables_dev,
+                       int max_blocks, float *out_dev, void *stream)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_decode_planned");
+    if (rc != NVK_OK)
+        return rc;
+    if (!plan || max_blocks <= 0 || (plan->num_seqs > 0 && (!q_dev || !block_tables_dev || !out_dev)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_planned: bad arguments");
+    DeviceScope scope(pool->device);
+    return enqueue_planned(pool, layer, plan, q_dev, block_tables_dev, max_blocks, out_dev,
+                           stream ? (hipStream_t)stream : pool->stream, nullptr, nullptr);
 }
 
 int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
@@ -687,7 +859,7 @@ int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, cons
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: flags %d", flags);
     DeviceScope scope(pool->device);
     return enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
-                          out_dev, flags, chunk_tokens, stream ? (hipStream_t)stream : pool->stream, nullptr, nullptr);
+                          out_dev, flags, chunk_tokens, stream ? (hipStream_t)stream : pool->stream);
 }
 
 int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q, const int *block_tables,
@@ -740,7 +912,7 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
     HIP_TRY(hipMemcpyAsync(dtab, block_tables, tab_b, hipMemcpyHostToDevice, pool->stream));
     HIP_TRY(hipMemcpyAsync(dctx, ctx_lens, ctx_b, hipMemcpyHostToDevice, pool->stream));
     rc = enqueue_decode(pool, layer, num_seqs, n_heads, dq, dtab, max_blocks, dctx, max_ctx, dout, flags, chunk_tokens,
-                        pool->stream, nullptr, nullptr);
+                        pool->stream);
     if (rc != NVK_OK)
         return rc;
     HIP_TRY(hipMemcpyAsync(out, dout, q_b, hipMemcpyDeviceToHost, pool->stream));
@@ -750,18 +922,33 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
 
 int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
                      const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx, float *out_dev,
-                     int flags, int chunk_tokens, int warmup, int iters, float *total_ms, float *attn_ms)
+                     int flags, int chunk_tokens, int replan_every, int warmup, int iters, float *total_ms,
+                     float *attn_ms)
 {
     int rc = check_pool_layer(pool, layer, "nvk_decode_bench");
     if (rc != NVK_OK)
         return rc;
-    if (iters < 0 || warmup < 0 || num_seqs <= 0 || iters > 100000)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_bench: need 0 <= iters <= 100000, warmup >= 0, num_seqs > 0");
+    if (iters < 0 || warmup < 0 || num_seqs <= 0 || iters > 100000 || replan_every < 1)
+        return nvk::fail(NVK_ERR_INVALID_ARG,
+                         "nvk_decode_bench: need 0 <= iters <= 100000, warmup >= 0, num_seqs > 0, replan_every >= 1");
     DeviceScope scope(pool->device);
-    hipStream_t st = pool->stream;
+    hipStream_t st   = pool->stream;
+    nvk_plan   *plan = nullptr;
+    rc               = own_plan_of(pool, &plan);
+    if (rc != NVK_OK)
+        return rc;
+    // layer-call i rebuilds the plan when i % replan_every == 0 (1: every call, like nvk_decode_device;
+    // L: once per L calls, like the L layers of one model step sharing their batch's plan)
+    auto one_call = [&](int i, hipEvent_t a, hipEvent_t b) -> int {
+        if (i % replan_every == 0) {
+            int r = build_plan(plan, num_seqs, n_heads, ctx_lens_dev, max_ctx, flags, chunk_tokens, st);
+            if (r != NVK_OK)
+                return r;
+        }
+        return enqueue_planned(pool, layer, plan, q_dev, block_tables_dev, max_blocks, out_dev, st, a, b);
+    };
     for (int i = 0; i < warmup; i++) {
-        rc = enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
-                            out_dev, flags, chunk_tokens, st, nullptr, nullptr);
+        rc = one_call(i, nullptr, nullptr);
         if (rc != NVK_OK)
             return rc;
     }
@@ -773,8 +960,8 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
     if (iters == 0)
         return NVK_OK;
 
-    // One timed region: ev_a .. ev_b brackets all `iters` layer-calls; inside it, when
-    // attn_ms is wanted, each attention-kernel launch is bracketed by its own event pair.
+    // One timed region: ev_a .. ev_b brackets all `iters` layer-calls (plan rebuilds included);
+    // inside it, when attn_ms is wanted, each attention-kernel launch has its own event pair.
     std::vector<hipEvent_t> ev(attn_ms ? (size_t)2 * iters : 0, nullptr);
     hipError_t              e = hipSuccess;
     for (auto &x : ev)
@@ -783,9 +970,7 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
     if (e == hipSuccess)
         e = hipEventRecord(pool->ev_a, st);
     for (int i = 0; i < iters && e == hipSuccess && rc == NVK_OK; i++)
-        rc = enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
-                            out_dev, flags, chunk_tokens, st, attn_ms ? ev[2 * i] : nullptr,
-                            attn_ms ? ev[2 * i + 1] : nullptr);
+        rc = one_call(i, attn_ms ? ev[2 * i] : nullptr, attn_ms ? ev[2 * i + 1] : nullptr);
     if (e == hipSuccess)
         e = hipEventRecord(pool->ev_b, st);
     if (e == hipSuccess)

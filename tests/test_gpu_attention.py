@@ -287,3 +287,48 @@ def test_block_placement_does_not_change_bits():
             ob = nv.decode(b, 0, q[None], ident[None], ctx, flags, chunk)
             assert np.array_equal(oa.view(np.uint32), ob.view(np.uint32))
     assert nb > ident.size
+
+
+def test_plan_reused_across_layers_matches_per_call_planning():
+    """One nvk_plan built from the batch's lengths serves every layer (device-pointer API)."""
+    from hipmem import DeviceArray
+
+    g = wl.Geometry(8, 2, 64, 16)
+    ctx = np.array([5, 300, 0, 64, 1000, 17, 129], np.int32)
+    work = wl.fragmented_workload("plan_reuse", ctx, g)
+    L = 3
+    with nv.PagedKVPool(L, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        for layer in range(L):
+            pool.fill_uniform(layer, 10 + layer, 20 + layer)
+        q = work.q()
+        qd, tabs, ctxd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(ctx)
+        plan = nv.DecodePlan(pool).build(work.num_seqs, g.n_heads, ctxd, work.max_ctx, nv.SPLIT_K, 128)
+        assert plan.info()["chunk_tokens"] == 128 and plan.info()["max_chunks"] == 8
+        for layer in range(L):
+            out = DeviceArray(np.full_like(q, np.nan))
+            plan.run(layer, qd, tabs, work.max_blocks, out)
+            pool.synchronize()
+            got = out.numpy()
+            want = nv.decode(pool, layer, q, work.block_tables, ctx, nv.SPLIT_K, 128)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # same plan, same bits
+            single = nv.decode(pool, layer, q, work.block_tables, ctx, nv.SINGLE_PASS)
+            assert_close(got, single, f"layer {layer}")
+        plan.close()
+
+
+def test_many_sequences_cross_plan_tiles():
+    """More sequences than the plan kernel has threads (several scan tiles), ragged, with empty ones."""
+    g = wl.Geometry(4, 2, 32, 8)
+    n = 2500
+    ctx = (wl.splitmix64(31, np.arange(n, dtype=np.uint64)) % np.uint64(70)).astype(np.int32)
+    ctx[::97] = 0
+    work = wl.fragmented_workload("many", ctx, g, slack=0.1)
+    q = work.q()
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(n)))
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, g.block_size, g.n_kv_heads, n_threads=8)
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for flags, chunk in ((nv.AUTO, 0), (nv.SPLIT_K, 16), (nv.SPLIT_K, 24), (nv.SINGLE_PASS, 0)):
+            got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, flags, chunk)
+            assert_close(got, want, f"flags={flags} chunk={chunk}")
+            assert not got[ctx == 0].any()
