@@ -60,6 +60,23 @@ def make_workload(name):
     raise SystemExit(f"unknown workload {name}")
 
 
+def profiled_traffic(work_name, kernel="nvk::nvk_decode_kernel<2, 4, true>"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
+    workload (profiles/r*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    corrections applied as MI355X_MICROARCH.md prescribes).  None when no profile matches."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            with open(path) as fh:
+                prof = json.load(fh)
+            if prof.get("workload") == work_name and kernel in prof.get("kernels", {}):
+                best = prof["kernels"][kernel].get("hbm_bytes_per_launch_corrected", best)
+        except (OSError, ValueError):
+            continue
+    return best
+
+
 def cpu_baseline(work, cores):
     """The reference's CPU attention timed on this host (rank 0, N=1 only).
 
@@ -151,6 +168,8 @@ def main():
                     help="rebuild the decode plan every N layer-calls inside the timed region "
                          "(1 = every call; 32 = as for the 32 layers of one model step)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: no per-kernel event pairs inside the timed region (roofline from step time)")
     args = ap.parse_args()
 
     import torch
@@ -183,7 +202,8 @@ def main():
 
     def run(warmup, iters):
         return nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
-                               flags, args.chunk, warmup, iters, replan_every=args.replan)
+                               flags, args.chunk, warmup, iters, replan_every=args.replan,
+                               want_attn=not args.no_kernel_events)
 
     def barrier():
         if world > 1:
@@ -194,6 +214,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     step_ms, attn_ms = run(0, args.steps)  # EXACTLY K steps; HIP events on the launch stream inside
+    if attn_ms is None:
+        attn_ms = step_ms
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     barrier()
@@ -231,7 +253,8 @@ def main():
             "event_ms_per_step": round(step_ms, 4),
             "roofline": {"bound": "hbm", "kernel": "nvk_decode_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "kernel_ms": round(attn_ms, 4), "algorithmic_bytes": nbytes},
+                         "traffic": profiled_traffic(work.name) if args.mode == "auto" and args.chunk == 0 else None,
+                         "kernel_ms": round(attn_ms, 4), "algorithmic_bytes": nbytes},
         }
         if world == 1 and not args.no_cpu:
             cores = min(16, os.cpu_count() or 1)

@@ -156,7 +156,7 @@ int nvk_decode_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const fl
  * nvk_decode_device; L = once per L calls, as for the L layers of a model step).
  *   total_ms  region time / iters (plan + attention + merge kernels + gaps)
  *   attn_ms   mean over the same region of the attention kernel's own
- *             duration, from an event pair around each of its launches
+ *             duration, from an event pair around every 8th of its launches
  * Either may be NULL; iters == 0 only warms up.  Returns after the region has
  * finished on the device. */
 int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
