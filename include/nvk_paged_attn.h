@@ -177,6 +177,15 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
 int nvk_paged_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
                         const int *block_table, float *att_scores, int num_tokens, int block_size, int head_dim,
                         int n_heads, int n_kv_heads);
+/* Drop-in for the reference's contiguous-cache twin, same ten arguments, host pointers.
+ * ref: Attention::standard_attention, include/core/attention.hpp:16-25 (body :26-76),
+ * called from LlamaModel::attention, include/core/model.hpp:419-430.
+ * key_cache/value_cache: one layer's [max_seq_len, n_kv_heads, head_dim] fp32 slab;
+ * tokens 0..pos are attended to (pos < 0 gives a zero row, as the reference's
+ * empty loops do).  Rows 0..pos are staged to the device for this call and run
+ * through the same kernels behind an identity block table.  att_scores ignored. */
+int nvk_standard_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
+                           float *att_scores, int pos, int head_dim, int n_heads, int n_kv_heads, int max_seq_len);
 /* Bind (pool, layer) as this thread's cache for nvk_paged_attention; pool NULL unbinds.
  * ref: the layer slicing in LlamaModel::attention, include/core/model.hpp:400-403. */
 int nvk_bind_pool(nvk_pool *pool, int layer);

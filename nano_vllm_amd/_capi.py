@@ -83,6 +83,7 @@ SIGNATURES = {
     "nvk_plan_info": (C.c_int, [_vp, _i]),
     "nvk_decode_planned": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "nvk_paged_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nvk_standard_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nvk_bind_pool": (C.c_int, [_vp, C.c_int]),
     "nvk_bm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "nvk_bm_destroy": (None, [_vp]),

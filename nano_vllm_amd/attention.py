@@ -62,6 +62,24 @@ def paged_attention(out: np.ndarray, q, key_cache, value_cache, block_table, att
                                               int(n_kv_heads)))
 
 
+def standard_attention(out: np.ndarray, q, key_cache, value_cache, att_scores, pos: int, head_dim: int,
+                       n_heads: int, n_kv_heads: int, max_seq_len: int) -> None:
+    """Drop-in for ``Attention::standard_attention`` (``include/core/attention.hpp:16-25``): the same
+    maths over one layer's contiguous ``[max_seq_len, n_kv_heads, head_dim]`` host cache, tokens 0..pos."""
+    if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags.c_contiguous):
+        raise TypeError("out must be a C-contiguous float32 ndarray (it is written in place)")
+    if out.size != n_heads * head_dim:
+        raise ValueError("out must hold n_heads*head_dim floats")
+    qh = _f32(q).reshape(-1)
+    if qh.size != n_heads * head_dim:
+        raise ValueError("q must hold n_heads*head_dim floats")
+    kc, vc = _f32(key_cache), _f32(value_cache)
+    if min(kc.size, vc.size) < int(max_seq_len) * int(n_kv_heads) * int(head_dim):
+        raise ValueError("caches must hold max_seq_len*n_kv_heads*head_dim floats")
+    _capi.check(_capi.lib.nvk_standard_attention(_ptr(out), _ptr(qh), _ptr(kc), _ptr(vc), None, int(pos),
+                                                 int(head_dim), int(n_heads), int(n_kv_heads), int(max_seq_len)))
+
+
 def decode(pool: PagedKVPool, layer: int, q, block_tables, ctx_lens, flags: int = AUTO,
            chunk_tokens: int = 0) -> np.ndarray:
     """One layer-call from host arrays: q [num_seqs, n_heads, head_dim] -> out of the same shape."""

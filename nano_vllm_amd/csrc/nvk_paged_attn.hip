@@ -450,6 +450,29 @@ thread_local int       t_bound_layer = 0;
 // thread-local scratch pool for the unbound (host-slab) form of the drop-in
 thread_local nvk_pool *t_scratch_pool = nullptr;
 
+
+// The calling thread's one-layer staging pool for the host-slab forms of the
+// drop-in entry points, (re)created when the geometry changes or it is too small.
+int scratch_pool_for(int block_size, int n_kv_heads, int head_dim, int nblk, nvk_pool **out)
+{
+    nvk_pool *sp = t_scratch_pool;
+    if (!sp || sp->block_size != block_size || sp->head_dim != head_dim || sp->n_kv_heads != n_kv_heads
+        || sp->num_blocks < nblk) {
+        if (sp)
+            nvk_pool_destroy(sp);
+        t_scratch_pool = nullptr;
+        int dev        = 0;
+        if (hipGetDevice(&dev) != hipSuccess)
+            dev = 0;
+        int rc = nvk_pool_create(1, std::max(2 * nblk, 64), block_size, n_kv_heads, head_dim, dev, &sp);
+        if (rc != NVK_OK)
+            return rc;
+        t_scratch_pool = sp;
+    }
+    *out = sp;
+    return NVK_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1050,32 +1073,56 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
         std::memset(out, 0, (size_t)n_heads * head_dim * sizeof(float));
         return NVK_OK;
     }
-    nvk_pool *sp = t_scratch_pool;
-    if (!sp || sp->block_size != block_size || sp->head_dim != head_dim || sp->n_kv_heads != n_kv_heads
-        || sp->num_blocks < nblk) {
-        if (sp)
-            nvk_pool_destroy(sp);
-        t_scratch_pool = nullptr;
-        int dev        = 0;
-        if (hipGetDevice(&dev) != hipSuccess)
-            dev = 0;
-        int rc = nvk_pool_create(1, std::max(nblk, 64), block_size, n_kv_heads, head_dim, dev, &sp);
-        if (rc != NVK_OK)
-            return rc;
-        t_scratch_pool = sp;
-    }
+    nvk_pool *sp = nullptr;
+    int       rc = scratch_pool_for(block_size, n_kv_heads, head_dim, nblk, &sp);
+    if (rc != NVK_OK)
+        return rc;
+    DeviceScope      scope(sp->device);
     const size_t     blk = (size_t)block_size * n_kv_heads * head_dim;
     std::vector<int> local((size_t)nblk);
     for (int i = 0; i < nblk; i++) {
         if (block_table[i] < 0)
             return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_paged_attention: block_table[%d]=%d is negative", i, block_table[i]);
-        int rc = nvk_pool_upload_block(sp, 0, i, key_cache + (size_t)block_table[i] * blk,
-                                       value_cache + (size_t)block_table[i] * blk);
-        if (rc != NVK_OK)
-            return rc;
+        // only the rows of the block that the sequence has reached (the last block is partly filled)
+        const size_t rows = (size_t)std::min(block_size, num_tokens - i * block_size) * n_kv_heads * head_dim;
+        HIP_TRY(hipMemcpyAsync(sp->k_layer(0) + (size_t)i * blk, key_cache + (size_t)block_table[i] * blk,
+                               rows * sizeof(float), hipMemcpyHostToDevice, sp->stream));
+        HIP_TRY(hipMemcpyAsync(sp->v_layer(0) + (size_t)i * blk, value_cache + (size_t)block_table[i] * blk,
+                               rows * sizeof(float), hipMemcpyHostToDevice, sp->stream));
         local[(size_t)i] = i;
     }
     return nvk_decode(sp, 0, 1, n_heads, q, local.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
+}
+
+int nvk_standard_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
+                           float *att_scores, int pos, int head_dim, int n_heads, int n_kv_heads, int max_seq_len)
+{
+    (void)att_scores;
+    if (!out || !q || !key_cache || !value_cache || head_dim <= 0 || n_heads <= 0 || n_kv_heads <= 0
+        || max_seq_len <= 0 || pos >= max_seq_len)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_standard_attention: bad arguments (pos=%d, max_seq_len=%d)", pos,
+                         max_seq_len);
+    if (pos < 0) { // the reference's loops over t <= pos do nothing and `out` stays zeroed (attention.hpp:29,39)
+        std::memset(out, 0, (size_t)n_heads * head_dim * sizeof(float));
+        return NVK_OK;
+    }
+    // A contiguous [max_seq_len, n_kv_heads, head_dim] cache is a paged pool whose
+    // table is the identity: rows 0..pos go to blocks 0.. of the staging pool in one copy each.
+    constexpr int kBlock     = 16;
+    const int     num_tokens = pos + 1;
+    const int     nblk       = (num_tokens + kBlock - 1) / kBlock;
+    nvk_pool     *sp         = nullptr;
+    int           rc         = scratch_pool_for(kBlock, n_kv_heads, head_dim, nblk, &sp);
+    if (rc != NVK_OK)
+        return rc;
+    DeviceScope  scope(sp->device);
+    const size_t bytes = (size_t)num_tokens * n_kv_heads * head_dim * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(sp->k_layer(0), key_cache, bytes, hipMemcpyHostToDevice, sp->stream));
+    HIP_TRY(hipMemcpyAsync(sp->v_layer(0), value_cache, bytes, hipMemcpyHostToDevice, sp->stream));
+    std::vector<int> ident((size_t)nblk);
+    for (int i = 0; i < nblk; i++)
+        ident[(size_t)i] = i;
+    return nvk_decode(sp, 0, 1, n_heads, q, ident.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
 }
 
 } // extern "C"

@@ -24,6 +24,21 @@ def test_golden_traces(golden_dir):
         assert got == t["results"], t["name"]
 
 
+DROPIN_PATH = os.path.join(ol.ROOT, "oracle", "_ref", "libnvk_ref_dropin.so")
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN_PATH), reason="oracle/_ref/libnvk_ref_dropin.so not built")
+def test_golden_traces_through_the_cpp_drop_in_class(golden_dir):
+    """include/nvk_dropin/scheduler/block_manager.hpp: the reference's class name and methods over nvk_bm_*,
+    driven through the same shim that recorded the traces from the reference's own class."""
+    lib = ol._load_ref(DROPIN_PATH)
+    with open(os.path.join(golden_dir, "block_manager_traces.json")) as fh:
+        traces = json.load(fh)["traces"]
+    for t in traces:
+        got = replay(BmCLib(lib, "ref_", t["num_blocks"], t["block_size"]), t["ops"])
+        assert got == t["results"], t["name"]
+
+
 def test_reference_error_behaviour():
     bm = nv.BlockManager(4, 16)
     assert [bm.allocate_block() for _ in range(5)] == [0, 1, 2, 3, -1]  # -1 when full (ref :30-33)

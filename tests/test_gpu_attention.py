@@ -76,6 +76,30 @@ def test_drop_in_signature(case, golden_dir):
             nv.bind_pool(None)
 
 
+@pytest.mark.parametrize("case", [c for c in ATTENTION_CASES if c["num_tokens"] > 0][:16],
+                         ids=[c["name"] for c in ATTENTION_CASES if c["num_tokens"] > 0][:16])
+def test_standard_attention_drop_in(case, golden_dir):
+    """nvk_standard_attention with the reference's ten arguments over a contiguous cache (golden F3:
+    the reference's standard_attention on the same rows, which equals its paged_attention bit for bit)."""
+    gold = np.load(os.path.join(golden_dir, "attention_cases.npz"))[case["name"] + "/std"]
+    q, k_pool, v_pool, table = attention_case_inputs(case)
+    H, KV, hd, bs, T = (case[k] for k in ("n_heads", "n_kv_heads", "head_dim", "block_size", "num_tokens"))
+    max_seq = T + 5
+    k_lin = np.full((max_seq, KV, hd), np.nan, np.float32)  # rows past pos must never be read
+    v_lin = np.full((max_seq, KV, hd), np.nan, np.float32)
+    for t in range(T):
+        k_lin[t] = k_pool[table[t // bs], t % bs]
+        v_lin[t] = v_pool[table[t // bs], t % bs]
+    out = np.full((H, hd), np.nan, np.float32)
+    nv.standard_attention(out, q, k_lin, v_lin, None, T - 1, hd, H, KV, max_seq)
+    assert_close(out, gold, "standard")
+    out2 = np.full((H, hd), np.nan, np.float32)
+    nv.standard_attention(out2, q, k_lin, v_lin, None, -1, hd, H, KV, max_seq)
+    assert not out2.any()
+    with pytest.raises(nv.NvkError):
+        nv.standard_attention(out2, q, k_lin, v_lin, None, max_seq, hd, H, KV, max_seq)
+
+
 def test_gather_is_bit_exact():
     """Block-table indexing and KV gather: identical bytes to the closed form of attention.hpp:109-115."""
     case = next(c for c in ATTENTION_CASES if c["name"].startswith("h12_kv3_d64_bs12"))  # non power-of-two block
