@@ -2,7 +2,7 @@
 """bench.py -- paged-attention decode on MI355X: achieved HBM GB/s and layer-call tokens/s.
 
     python bench.py --gpus N --steps K --warmup W [--workload config2|config3|config4|5a|5b]
-                    [--mode auto|single|split] [--chunk T] [--no-cpu]
+                    [--shard seq|heads] [--mode auto|single|split] [--chunk T] [--no-cpu]
 
 A "step" is one layer-call: one new token for every sequence of the batch in
 one layer.  At N=1 the default workload is BASELINE.json
@@ -10,6 +10,9 @@ configs[1] (64 seqs x 2K ctx, uniform block tables, fp32 KV, 32q/8kv heads x
 128).  For N>1 the path is sequence-sharded: every rank owns a private pool and
 its own batch of that shape, there is no data-path collective, and the job's
 throughput is the sum over ranks over the slowest rank's time (weak scaling).
+--shard heads is the head-group variant: every rank holds n_kv_heads/N kv-heads
+of ALL sequences and the out slices are joined by one RCCL all-gather per
+layer-call, inside the timed region (strong scaling: the batch is fixed).
 
 Inputs are resident in HBM before the timed region (the pool is filled by a
 device kernel; q / block tables / lengths are device tensors).  Rank 0 prints
@@ -34,7 +37,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def make_workload(name):
+def make_workload(name, rank=0):
     from nano_vllm_amd import workloads as wl
 
     if name == "config2":
@@ -54,7 +57,7 @@ def make_workload(name):
     if name == "config2f":  # diagnostic: config 2's uniform lengths behind fragmented tables
         return wl.fragmented_workload("decode_64x2048_fragmented", np.full(64, 2048, np.int32))
     if name == "5a":
-        return wl.config5a(512)
+        return wl.config5a(512, first_seq=512 * rank)  # rank r's slice of the 4096-sequence batch
     if name == "5b":
         return wl.config5b(512)
     raise SystemExit(f"unknown workload {name}")
@@ -162,6 +165,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config2")
+    ap.add_argument("--shard", default="seq", choices=["seq", "heads"],
+                    help="seq: a private batch per GPU, no collective (default); heads: kv-head groups per GPU, "
+                         "one RCCL all-gather of out per layer-call")
     ap.add_argument("--mode", default="auto", choices=["auto", "single", "split"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--replan", type=int, default=1,
@@ -188,12 +194,25 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
-    work = make_workload(args.workload)
+    work = make_workload(args.workload, rank)
     g = work.geom
     flags = {"auto": nv.AUTO, "single": nv.SINGLE_PASS, "split": nv.SPLIT_K}[args.mode]
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if args.shard == "heads":
+        # head-group variant: this rank's pool holds n_kv_heads/world kv-heads of every sequence
+        from nano_vllm_amd import sharding as sh
+        from nano_vllm_amd import workloads as wl
+
+        hs = sh.HeadShard(rank, world, g.n_heads, g.n_kv_heads)
+        g = wl.Geometry(hs.local_heads, hs.local_kv_heads, g.head_dim, g.block_size)
+        work = wl.Workload(work.name + f"_heads{rank}of{world}", g, work.num_blocks, work.ctx_lens, work.block_tables,
+                           work.fragmented)
     pool = nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=local_rank)
-    pool.fill_uniform(0, 1, 2)
+    pool.fill_uniform(0, 1 + 16 * rank, 2 + 16 * rank)
     q = torch.from_numpy(work.q()).to(dev)
     tabs = torch.from_numpy(work.block_tables).to(dev)
     ctx = torch.from_numpy(work.ctx_lens).to(dev)
@@ -205,20 +224,48 @@ def main():
                                flags, args.chunk, warmup, iters, replan_every=args.replan,
                                want_attn=not args.no_kernel_events)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    if args.shard == "seq":
+        run(args.warmup, 0)  # W untimed steps (also sizes the split-K workspace)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        step_ms, attn_ms = run(0, args.steps)  # EXACTLY K steps; HIP events on the launch stream inside
+        if attn_ms is None:
+            attn_ms = step_ms
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        barrier()
+    else:
+        # attention on torch's current stream, then the all-gather on the same stream: K x (decode + gather)
+        # (an explicit side stream: the C ABI reads a NULL stream as "the pool's own stream", and torch's
+        # default stream IS the NULL stream, which would leave the gather unordered with the kernels)
+        gathered = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(side)
+        stream = side.cuda_stream
+        assert stream != 0
 
-    run(args.warmup, 0)  # W untimed steps (also sizes the split-K workspace)
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    step_ms, attn_ms = run(0, args.steps)  # EXACTLY K steps; HIP events on the launch stream inside
-    if attn_ms is None:
-        attn_ms = step_ms
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    barrier()
+        def step():
+            nv.decode_device(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
+                             flags, args.chunk, stream=stream)
+            hs.all_gather_out(out, gathered)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        barrier()
+        step_ms = ev0.elapsed_time(ev1) / args.steps
+        _, attn_ms = run(2, 16)  # the attention kernel alone in this rank's shape, HIP events on the pool's stream
+        torch.cuda.synchronize()
 
     if world > 1:
         t = torch.tensor([wall, step_ms, attn_ms], dtype=torch.float64, device=dev)
@@ -230,6 +277,7 @@ def main():
         ms_per_step = wall * 1e3 / args.steps
         value = nbytes * world / (ms_per_step * 1e-3) / 1e9
         achieved = nbytes / (attn_ms * 1e-3) / 1e9
+        seqs_all = work.num_seqs * (world if args.shard == "seq" else 1)  # head shards all hold the same batch
         line = {
             "metric": "paged_attn_decode_achieved_hbm_GBps",
             "value": round(value, 1),
@@ -239,17 +287,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.shard == "seq" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": work.name, "num_seqs_per_gpu": work.num_seqs, "total_ctx_tokens_per_gpu":
                        work.total_tokens, "n_heads": g.n_heads, "n_kv_heads": g.n_kv_heads, "head_dim": g.head_dim,
                        "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode, "replan_every": args.replan,
-                       "parallelism": f"sequence-sharded x{world}, no collective"},
+                       "parallelism": (f"sequence-sharded x{world}, no collective" if args.shard == "seq" else
+                                       f"head-sharded x{world}, one RCCL all-gather of out per layer-call")},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
-            "tokens_per_s": round(work.num_seqs * world / (ms_per_step * 1e-3), 1),
-            "tokens_per_s_32_layer_model": round(work.num_seqs * world / (ms_per_step * 1e-3) / 32.0, 1),
+            "tokens_per_s": round(seqs_all / (ms_per_step * 1e-3), 1),
+            "tokens_per_s_32_layer_model": round(seqs_all / (ms_per_step * 1e-3) / 32.0, 1),
             "event_ms_per_step": round(step_ms, 4),
             "roofline": {"bound": "hbm", "kernel": "nvk_decode_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

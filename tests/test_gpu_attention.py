@@ -356,3 +356,29 @@ def test_many_sequences_cross_plan_tiles():
             got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, flags, chunk)
             assert_close(got, want, f"flags={flags} chunk={chunk}")
             assert not got[ctx == 0].any()
+
+
+def test_head_sharded_pools_reproduce_the_full_result_bitwise():
+    """SURVEY.md 8e, head-sharded variant, emulated on one GPU: G pools of n_kv_heads/G kv-heads each, the rank
+    slices of q, and the gathered layout [G, n, H/G, hd] assembled back -- every bit equal to the one-pool result
+    (the all-gather itself is covered over gloo in tests/test_sharding_gloo.py)."""
+    from nano_vllm_amd import sharding as sh
+
+    g = wl.Geometry(16, 8, 128, 16)
+    ctx = np.array([700, 1, 64, 2049, 0, 130], np.int32)
+    work = wl.fragmented_workload("head_shards", ctx, g)
+    q = work.q()
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(work.num_seqs)))
+    nb = k_host.shape[0]
+    with pool_from_host(k_host, v_host) as full_pool:
+        full = nv.decode(full_pool, 0, q, tabs, c, nv.SPLIT_K, 512)
+    for world in (2, 8):
+        parts = []
+        for rank in range(world):
+            hs = sh.HeadShard(rank, world, g.n_heads, g.n_kv_heads)
+            with nv.PagedKVPool(1, nb, g.block_size, hs.local_kv_heads, g.head_dim) as pool:
+                for b in range(nb):
+                    pool.upload_block(0, b, hs.local_kv_block(k_host[b]), hs.local_kv_block(v_host[b]))
+                parts.append(nv.decode(pool, 0, hs.local_q(q), tabs, c, nv.SPLIT_K, 512))
+        got = sh.assemble_heads(np.stack(parts))
+        assert np.array_equal(got.view(np.uint32), full.view(np.uint32)), world
