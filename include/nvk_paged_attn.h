@@ -85,6 +85,21 @@ int nvk_pool_append(nvk_pool *pool, int layer, int physical_block, int block_off
 int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *k_rows, const float *v_rows,
                           const int *block_tables, int max_blocks, const int *positions, int ptr_kind);
 
+/* RoPE fused with the batched KV append: for each sequence s, with
+ * pos = positions[s], rotate q[s] IN PLACE and rotate k_rows[s] on its way into the pool slot
+ * of token pos; v_rows[s] is copied there unchanged.  k_rows/v_rows are only read.
+ * ref: Ops::apply_rope, include/ops/positional.hpp:13-39, called at include/core/model.hpp:169-175,
+ *      followed by the append at include/core/model.hpp:190-207.
+ *   q       [num_seqs, n_heads, head_dim]       k_rows, v_rows [num_seqs, n_kv_heads*head_dim]
+ *   rope_theta  the reference's config.rope_theta (include/core/model.hpp:40: 10000)
+ * The frequencies 1/powf(theta, i/head_dim) come from the host libm (a 1-ulp difference there is
+ * amplified by pos); cos/sin are evaluated in fp64 on the device; the rotation is unfused fp32.
+ * ptr_kind NVK_PTR_HOST: validates, stages, runs, copies q back, synchronises.
+ * NVK_PTR_DEVICE: asynchronous on `stream` (NULL = the pool's stream). */
+int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_heads, float *q, const float *k_rows,
+                               const float *v_rows, const int *block_tables, int max_blocks, const int *positions,
+                               float rope_theta, int ptr_kind, void *stream);
+
 /* Whole-block transfers, host pointers, [block_size, n_kv_heads, head_dim] floats each. */
 int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const float *k_block,
                           const float *v_block);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "nvk_pool_synchronize": (C.c_int, [_vp]),
     "nvk_pool_append": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "nvk_pool_append_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "nvk_pool_rope_append_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp,
+                                             C.c_float, C.c_int, _vp]),
     "nvk_pool_upload_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "nvk_pool_download_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "nvk_pool_gather": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),

@@ -596,6 +596,65 @@ __global__ void nvk_append_kernel(float *__restrict__ k_layer, float *__restrict
     }
 }
 
+// ---- RoPE fused with the batched KV append --------------
+// Reference: Ops::apply_rope (ops/positional.hpp:13-39) as called at model.hpp:169-175,
+// then the append at model.hpp:190-207.  grid.x = sequences.  Per sequence:
+//   angle_p = (float)pos * inv_freq[p],  inv_freq[p] = 1 / powf(theta, 2p / head_dim)  (host libm, exactly
+//   the reference's expression: a 1-ulp difference in the frequency would be amplified by pos);
+//   cos/sin evaluated in fp64 and rounded once, so they agree with a correctly rounded cosf/sinf;
+//   the rotation itself is unfused fp32 mul/sub/add (rope_rotate), the order of positional.hpp:26-27, :35-36.
+// q is rotated in place (as the reference rotates state.q); the rotated K row and the V row go
+// straight to the pool slot of token `pos` (k_rows itself is left untouched).
+// (hipcc contracts a*b - c*d into an fma by default, and __fmul_rn/__fsub_rn are plain operators
+// in this ROCm: the pragma is what keeps the four products and the two sums separately rounded)
+__device__ __forceinline__ float2 rope_rotate(float2 v, float2 cs)
+{
+#pragma clang fp contract(off)
+    const float xc = v.x * cs.x, ys = v.y * cs.y, xs = v.x * cs.y, yc = v.y * cs.x;
+    return make_float2(xc - ys, xs + yc);
+}
+
+__global__ void __launch_bounds__(256)
+    nvk_rope_append_kernel(float *__restrict__ k_layer, float *__restrict__ v_layer, float *__restrict__ q,
+                           const float *__restrict__ k_rows, const float *__restrict__ v_rows,
+                           const int *__restrict__ block_tables, int max_blocks, const int *__restrict__ positions,
+                           const float *__restrict__ inv_freq, int num_blocks, int block_size, unsigned bs_magic,
+                           int n_heads, int n_kv_heads, int head_dim)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 s_cs[]; // [head_dim / 2] (cos, sin)
+    const int seq = blockIdx.x;
+    const int pos = positions[seq];
+    if (pos < 0)
+        return;
+    const int half = head_dim >> 1;
+    for (int p = threadIdx.x; p < half; p += blockDim.x) {
+        const float  angle = (float)pos * inv_freq[p];
+        double       sn, cs;
+        sincos((double)angle, &sn, &cs);
+        s_cs[p] = make_float2((float)cs, (float)sn);
+    }
+    __syncthreads();
+
+    auto rotate = [](float2 v, float2 cs) { return rope_rotate(v, cs); };
+
+    float2 *q2 = reinterpret_cast<float2 *>(q + (int64_t)seq * n_heads * head_dim);
+    for (int i = threadIdx.x; i < n_heads * half; i += blockDim.x)
+        q2[i] = rotate(q2[i], s_cs[i % half]);
+
+    const int     row_len = n_kv_heads * head_dim;
+    const int     blk     = token_block(pos, bs_magic);
+    const int     off     = token_offset(pos, blk, block_size);
+    const int     pb      = clamp_block(block_tables[(int64_t)seq * max_blocks + blk], num_blocks);
+    const int64_t at      = ((int64_t)pb * block_size + off) * row_len;
+    const float2 *k2      = reinterpret_cast<const float2 *>(k_rows + (int64_t)seq * row_len);
+    float2       *kd      = reinterpret_cast<float2 *>(k_layer + at);
+    for (int i = threadIdx.x; i < n_kv_heads * half; i += blockDim.x)
+        kd[i] = rotate(k2[i], s_cs[i % half]);
+    for (int i = threadIdx.x * 4; i < row_len; i += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(v_layer + at + i) =
+            *reinterpret_cast<const float4 *>(v_rows + (int64_t)seq * row_len + i);
+}
+
 // ---- synthetic fill: the counter-based generator of SURVEY.md 8d -------------
 __device__ __forceinline__ float uniform_from_counter(uint64_t seed, uint64_t index)
 {

@@ -105,6 +105,10 @@ struct nvk_pool
 
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
 
+    // RoPE inverse frequencies for (rope_theta, head_dim), computed on the host with libm
+    float *rope_inv_freq = nullptr; // [head_dim / 2] on the device
+    float  rope_theta    = 0.f;     // 0 = table not built
+
     float *k_layer(int layer) const { return k + (size_t)layer * layer_floats; }
     float *v_layer(int layer) const { return v + (size_t)layer * layer_floats; }
     int    row_len() const { return n_kv_heads * head_dim; }
@@ -568,6 +572,8 @@ int nvk_pool_destroy(nvk_pool *pool)
     if (pool->ws_ml)
         (void)hipFree(pool->ws_ml);
     free_plan(pool->own_plan);
+    if (pool->rope_inv_freq)
+        (void)hipFree(pool->rope_inv_freq);
     if (pool->stage)
         (void)hipFree(pool->stage);
     if (pool->ev_a)
@@ -695,6 +701,87 @@ int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *
     HIP_TRY(hipGetLastError());
     if (ptr_kind == NVK_PTR_HOST)
         HIP_TRY(hipStreamSynchronize(pool->stream));
+    return NVK_OK;
+}
+
+int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_heads, float *q, const float *k_rows,
+                               const float *v_rows, const int *block_tables, int max_blocks, const int *positions,
+                               float rope_theta, int ptr_kind, void *stream)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_rope_append_batch");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_seqs < 0 || max_blocks <= 0 || n_heads <= 0 || !(rope_theta > 0.f)
+        || (num_seqs > 0 && (!q || !k_rows || !v_rows || !block_tables || !positions)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: bad arguments");
+    if (pool->head_dim % 2 != 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: head_dim must be even");
+    if (num_seqs == 0)
+        return NVK_OK;
+    DeviceScope scope(pool->device);
+    hipStream_t st   = (ptr_kind == NVK_PTR_DEVICE && stream) ? (hipStream_t)stream : pool->stream;
+    const int   hd   = pool->head_dim;
+    const int   half = hd / 2;
+
+    // inv_freq[p] = 1 / powf(theta, 2p / head_dim): the reference's own expression (positional.hpp:16)
+    // through the host libm, rebuilt only when theta changes
+    if (!pool->rope_inv_freq || pool->rope_theta != rope_theta) {
+        std::vector<float> freq((size_t)half);
+        for (int i = 0; i < hd; i += 2)
+            freq[(size_t)(i / 2)] = 1.0f / powf(rope_theta, (float)i / hd);
+        if (!pool->rope_inv_freq)
+            HIP_TRY(hipMalloc(&pool->rope_inv_freq, (size_t)half * sizeof(float)));
+        HIP_TRY(hipDeviceSynchronize()); // an earlier launch on another stream may still read the old table
+        HIP_TRY(hipMemcpy(pool->rope_inv_freq, freq.data(), (size_t)half * sizeof(float), hipMemcpyHostToDevice));
+        pool->rope_theta = rope_theta;
+    }
+
+    const int    row = pool->row_len();
+    float       *dq  = q;
+    const float *dk = k_rows, *dv = v_rows;
+    const int   *dt = block_tables, *dp = positions;
+    const size_t q_b = (size_t)num_seqs * n_heads * hd * sizeof(float);
+    if (ptr_kind == NVK_PTR_HOST) {
+        for (int s = 0; s < num_seqs; s++) {
+            const int pos = positions[s];
+            if (pos < 0 || pos / pool->block_size >= max_blocks)
+                return nvk::fail(NVK_ERR_INVALID_ARG,
+                                 "nvk_pool_rope_append_batch: position %d of sequence %d outside its table", pos, s);
+            const int pb = block_tables[(size_t)s * max_blocks + pos / pool->block_size];
+            if (pb < 0 || pb >= pool->num_blocks)
+                return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_rope_append_batch: block %d of sequence %d outside [0,%d)",
+                                 pb, s, pool->num_blocks);
+        }
+        const size_t rows_b = (size_t)num_seqs * row * sizeof(float);
+        const size_t tab_b  = (size_t)num_seqs * max_blocks * sizeof(int);
+        const size_t pos_b  = (size_t)num_seqs * sizeof(int);
+        auto         al     = [](size_t b) { return (b + 255) / 256 * 256; };
+        rc = ensure_stage(pool, al(q_b) + 2 * al(rows_b) + al(tab_b) + al(pos_b));
+        if (rc != NVK_OK)
+            return rc;
+        char *base = pool->stage;
+        dq         = (float *)base;
+        dk         = (const float *)(base + al(q_b));
+        dv         = (const float *)(base + al(q_b) + al(rows_b));
+        dt         = (const int *)(base + al(q_b) + 2 * al(rows_b));
+        dp         = (const int *)(base + al(q_b) + 2 * al(rows_b) + al(tab_b));
+        HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)dk, k_rows, rows_b, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)dv, v_rows, rows_b, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)dt, block_tables, tab_b, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)dp, positions, pos_b, hipMemcpyHostToDevice, st));
+    }
+    else if (ptr_kind != NVK_PTR_DEVICE) {
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: ptr_kind %d", ptr_kind);
+    }
+    hipLaunchKernelGGL(nvk::nvk_rope_append_kernel, dim3((unsigned)num_seqs), dim3(256), (size_t)half * sizeof(float2), st,
+                       pool->k_layer(layer), pool->v_layer(layer), dq, dk, dv, dt, max_blocks, dp, pool->rope_inv_freq,
+                       pool->num_blocks, pool->block_size, pool->bs_magic, n_heads, pool->n_kv_heads, hd);
+    HIP_TRY(hipGetLastError());
+    if (ptr_kind == NVK_PTR_HOST) {
+        HIP_TRY(hipMemcpyAsync(q, dq, q_b, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return NVK_OK;
 }
 

@@ -126,6 +126,35 @@ class PagedKVPool:
                                                     _devptr(v_rows_dev), _devptr(block_tables_dev), int(max_blocks),
                                                     _devptr(positions_dev), _capi.PTR_DEVICE))
 
+    def rope_append_batch(self, layer: int, q, k_rows, v_rows, block_tables, positions,
+                          rope_theta: float = 10000.0) -> np.ndarray:
+        """RoPE + append for one new token per sequence, host arrays (``Ops::apply_rope`` at
+        ``model.hpp:169-175`` then the append at ``:190-207``).  Returns the rotated q
+        [num_seqs, n_heads, head_dim]; the rotated K rows and the V rows are in the pool."""
+        tabs = _i32(block_tables)
+        if tabs.ndim != 2:
+            raise ValueError("block_tables must be [num_seqs, max_blocks]")
+        n, max_blocks = tabs.shape
+        qh = np.array(q, dtype=np.float32, order="C", copy=True)
+        if qh.ndim != 3 or qh.shape[0] != n or qh.shape[2] != self.head_dim:
+            raise ValueError("q must be [num_seqs, n_heads, head_dim]")
+        k = _f32(k_rows).reshape(n, self.row_len)
+        v = _f32(v_rows).reshape(n, self.row_len)
+        pos = _i32(positions).reshape(n)
+        _capi.check(_capi.lib.nvk_pool_rope_append_batch(self.handle, int(layer), n, int(qh.shape[1]), _ptr(qh),
+                                                         _ptr(k), _ptr(v), _ptr(tabs), max_blocks, _ptr(pos),
+                                                         float(rope_theta), _capi.PTR_HOST, None))
+        return qh
+
+    def rope_append_batch_device(self, layer: int, num_seqs: int, n_heads: int, q_dev, k_rows_dev, v_rows_dev,
+                                 block_tables_dev, max_blocks: int, positions_dev, rope_theta: float = 10000.0,
+                                 stream=None) -> None:
+        _capi.check(_capi.lib.nvk_pool_rope_append_batch(self.handle, int(layer), int(num_seqs), int(n_heads),
+                                                         _devptr(q_dev), _devptr(k_rows_dev), _devptr(v_rows_dev),
+                                                         _devptr(block_tables_dev), int(max_blocks),
+                                                         _devptr(positions_dev), float(rope_theta), _capi.PTR_DEVICE,
+                                                         _devptr(stream)))
+
     def upload_block(self, layer: int, physical_block: int, k_block, v_block) -> None:
         shape = (self.block_size, self.n_kv_heads, self.head_dim)
         k = _f32(k_block).reshape(shape)

@@ -591,10 +591,12 @@ static void rmsnorm(float *y, const float *x, const float *g, int n) /* ops/norm
         y[i] = x[i] * r * g[i];
 }
 
-static void rope(float *q, float *k, int pos, int head_dim, int n_heads, int n_kv_heads) /* ops/positional.hpp:13-39 */
+/* Restates Ops::apply_rope, include/ops/positional.hpp:13-39: pairs (i, i+1) of every
+ * q-head and kv-head rotated in place by angle pos / theta^(i/head_dim). */
+void oracle_apply_rope(float *q, float *k, int pos, int head_dim, int n_heads, int n_kv_heads, float theta)
 {
     for (int i = 0; i < head_dim; i += 2) {
-        const float freq = 1.0f / powf(10000.0f, (float)i / head_dim);
+        const float freq = 1.0f / powf(theta, (float)i / head_dim);
         const float ang  = pos * freq;
         const float c = cosf(ang), s = sinf(ang);
         for (int h = 0; h < n_heads; h++) {
@@ -626,7 +628,7 @@ int oracle_model_forward(oracle_model *m, int token, int pos, float *logits_out)
         gemv(m->q, m->xb, m->wq + (size_t)l * D * QD, D, QD);
         gemv(m->k, m->xb, m->wk + (size_t)l * D * KD, D, KD);
         gemv(m->v, m->xb, m->wv + (size_t)l * D * KD, D, KD);
-        rope(m->q, m->k, pos, hd, m->n_heads, m->n_kv_heads);
+        oracle_apply_rope(m->q, m->k, pos, hd, m->n_heads, m->n_kv_heads, 10000.0f); /* config.rope_theta, model.hpp:40 */
 
         if (pos % m->block_size == 0) { /* :181-187 */
             const int fresh = oracle_bm_allocate_block(m->bm);

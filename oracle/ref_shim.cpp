@@ -15,6 +15,7 @@
 //   BlockManager                    include/scheduler/block_manager.hpp:14-283
 //   LlamaModel                      include/core/model.hpp:104-433
 //   Sampler (greedy branch)         include/core/sampler.hpp:24-29
+//   Ops::apply_rope                 include/ops/positional.hpp:13-39
 
 #include <cstdio>
 #include <cstring>
@@ -88,6 +89,12 @@ void ref_paged_attention_batch(float *out, const float *q, const float *key_cach
                                    key_cache, value_cache, block_tables + (size_t)s * max_blocks, att_scores,
                                    ctx_lens[s], block_size, head_dim, n_heads, n_kv_heads);
     }
+}
+
+// Ops::apply_rope, include/ops/positional.hpp:13-39 (reached through core/model.hpp)
+void ref_apply_rope(float *q, float *k, int pos, int head_dim, int n_heads, int n_kv_heads, float theta)
+{
+    Ops::apply_rope(q, k, pos, head_dim, n_heads, n_kv_heads, theta);
 }
 
 // ------------------------------------------------------------- BlockManager

@@ -38,6 +38,8 @@ def _load_oracle(path):
     lib.oracle_standard_attention.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]
     lib.oracle_decode_batch.restype = _i
     lib.oracle_decode_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i]
+    lib.oracle_apply_rope.restype = None
+    lib.oracle_apply_rope.argtypes = [_vp, _vp, _i, _i, _i, _i, C.c_float]
     lib.oracle_kv_append.restype = None
     lib.oracle_kv_append.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]
     lib.oracle_bm_create.restype = _vp
@@ -90,6 +92,9 @@ def _load_ref(path):
     lib.ref_standard_attention.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]
     lib.ref_paged_attention_batch.restype = None
     lib.ref_paged_attention_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i]
+    if hasattr(lib, "ref_apply_rope"):
+        lib.ref_apply_rope.restype = None
+        lib.ref_apply_rope.argtypes = [_vp, _vp, _i, _i, _i, _i, C.c_float]
     lib.ref_bm_create.restype = _vp
     lib.ref_bm_create.argtypes = [_i, _i]
     lib.ref_bm_destroy.restype = None
@@ -203,3 +208,11 @@ def oracle_fill_uniform(seed, first, count):
     out = np.empty(count, np.float32)
     ORACLE.oracle_fill_uniform(_p(out), int(seed), int(first), int(count))
     return out
+
+
+def apply_rope(lib_fn, q, k, pos, head_dim, n_heads, n_kv_heads, theta=10000.0):
+    """{oracle,ref}_apply_rope on copies: returns (q_rot [n_heads, hd], k_rot [n_kv_heads, hd])."""
+    q = np.array(q, np.float32, copy=True).reshape(n_heads, head_dim)
+    k = np.array(k, np.float32, copy=True).reshape(n_kv_heads, head_dim)
+    lib_fn(_p(q), _p(k), int(pos), int(head_dim), int(n_heads), int(n_kv_heads), C.c_float(theta))
+    return q, k

@@ -382,3 +382,64 @@ def test_head_sharded_pools_reproduce_the_full_result_bitwise():
                 parts.append(nv.decode(pool, 0, hs.local_q(q), tabs, c, nv.SPLIT_K, 512))
         got = sh.assemble_heads(np.stack(parts))
         assert np.array_equal(got.view(np.uint32), full.view(np.uint32)), world
+
+
+@pytest.mark.parametrize("geom", [(6, 6, 48, 16), (32, 8, 128, 16), (8, 2, 64, 32), (4, 4, 20, 8)],
+                         ids=["g_tiny", "g_llama", "h8kv2d64", "d20"])
+def test_rope_append_batch_matches_reference_rope_then_append(geom):
+    """SURVEY.md 8f row f1: Ops::apply_rope (positional.hpp:13-39) + the append (model.hpp:190-207) in one kernel.
+    Rotated q and the K/V rows that land in the pool are compared with the checker; then attention over them."""
+    H, KV, hd, bs = geom
+    n, max_blocks = 13, 6
+    nb = n * max_blocks + 5
+    tabs = wl.shuffled_permutation(nb, 17)[: n * max_blocks].reshape(n, max_blocks).astype(np.int32)
+    pos = (wl.splitmix64(5, np.arange(n, dtype=np.uint64)) % np.uint64(max_blocks * bs)).astype(np.int32)
+    pos[0], pos[1] = 0, max_blocks * bs - 1
+    q = (wl.uniform(31, 0, n * H * hd) * np.float32(2)).reshape(n, H, hd)
+    k = (wl.uniform(32, 0, n * KV * hd) * np.float32(2)).reshape(n, KV, hd)
+    v = wl.uniform(33, 0, n * KV * hd).reshape(n, KV, hd)
+    for theta in (10000.0, 500000.0):
+        with nv.PagedKVPool(2, nb, bs, KV, hd) as pool:
+            q_rot = pool.rope_append_batch(1, q, k, v, tabs, pos, theta)
+            exact = total = 0
+            for s in range(n):
+                want_q, want_k = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q[s], k[s], int(pos[s]), hd, H, KV, theta)
+                kb, vb = pool.download_block(1, int(tabs[s, pos[s] // bs]))
+                got_k, got_v = kb[pos[s] % bs], vb[pos[s] % bs]
+                assert np.array_equal(got_v.view(np.uint32), v[s].view(np.uint32))  # V is a plain copy: bit-exact
+                assert_close(q_rot[s], want_q, f"q seq {s} pos {pos[s]}")
+                assert_close(got_k, want_k, f"k seq {s} pos {pos[s]}")
+                # far tighter than the bar in practice: cos/sin differ from libm's by at most one rounding
+                assert np.abs(q_rot[s] - want_q).max() <= 4e-7 * max(1.0, float(np.abs(want_q).max()))
+                exact += int((q_rot[s].view(np.uint32) == want_q.view(np.uint32)).sum())
+                total += want_q.size
+            assert exact >= 0.98 * total, (exact, total)
+            k0, _ = pool.download_block(0, int(tabs[0, 0]))
+            assert not k0.any()  # the other layer is untouched
+
+
+def test_rope_append_then_decode_like_a_batched_model_step():
+    """positions advance token by token for a small batch: rope+append, then decode, against the checker's
+    own rope -> append -> paged_attention on a host pool (the order of LlamaModel::forward, model.hpp:169-221)."""
+    H, KV, hd, bs = 8, 2, 64, 16
+    n, steps = 5, 37
+    max_blocks = (steps + bs - 1) // bs
+    nb = n * max_blocks
+    tabs = wl.shuffled_permutation(nb, 3).reshape(n, max_blocks).astype(np.int32)
+    host_k = np.zeros((nb, bs, KV, hd), np.float32)
+    host_v = np.zeros_like(host_k)
+    rng = np.random.default_rng(12)
+    with nv.PagedKVPool(1, nb, bs, KV, hd) as pool:
+        for t in range(steps):
+            q = rng.standard_normal((n, H, hd), dtype=np.float32)
+            k = rng.standard_normal((n, KV, hd), dtype=np.float32)
+            v = rng.standard_normal((n, KV, hd), dtype=np.float32)
+            pos = np.full(n, t, np.int32)
+            q_rot = pool.rope_append_batch(0, q, k, v, tabs, pos)
+            got = nv.decode(pool, 0, q_rot, tabs, pos + 1)
+            for s in range(n):
+                wq, wk = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q[s], k[s], t, hd, H, KV)
+                pb = int(tabs[s, t // bs])
+                host_k[pb, t % bs], host_v[pb, t % bs] = wk, v[s]
+                want = ol.oracle_paged_attention(wq, host_k, host_v, tabs[s], t + 1, bs, hd, H, KV)
+                assert_close(got[s], want, f"step {t} seq {s}")

@@ -60,3 +60,15 @@ def test_block_manager_scripts_and_random_ops():
         a = replay(BmCLib(ol.ORACLE, "oracle_", nb, 4), ops)
         b = replay(BmCLib(ol.REF, "ref_", nb, 4), ops)
         assert a == b, seed
+
+
+def test_apply_rope_bit_exact():
+    for seed, (H, KV, hd) in enumerate([(6, 6, 48), (32, 8, 128), (8, 2, 64), (4, 4, 20), (2, 1, 256)]):
+        q = uniform(300 + seed, 0, H * hd) * np.float32(3)
+        k = uniform(400 + seed, 0, KV * hd) * np.float32(3)
+        for pos in (0, 1, 15, 255, 2047, 32767, 1_000_003):
+            for theta in (10000.0, 500000.0):
+                a = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q, k, pos, hd, H, KV, theta)
+                b = ol.apply_rope(ol.REF.ref_apply_rope, q, k, pos, hd, H, KV, theta)
+                assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
