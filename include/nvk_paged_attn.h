@@ -91,7 +91,8 @@ int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *
  * ref: Ops::apply_rope, include/ops/positional.hpp:13-39, called at include/core/model.hpp:169-175,
  *      followed by the append at include/core/model.hpp:190-207.
  *   q       [num_seqs, n_heads, head_dim]       k_rows, v_rows [num_seqs, n_kv_heads*head_dim]
- *   rope_theta  the reference's config.rope_theta (include/core/model.hpp:40: 10000)
+ *   rope_theta  the reference's config.rope_theta (include/core/model.hpp:40: 10000);
+ *               0 = no rotation: a plain batched append on `stream` (q is not touched, may be NULL)
  * The frequencies 1/powf(theta, i/head_dim) come from the host libm (a 1-ulp difference there is
  * amplified by pos); cos/sin are evaluated in fp64 on the device; the rotation is unfused fp32.
  * ptr_kind NVK_PTR_HOST: validates, stages, runs, copies q back, synchronises.
@@ -204,6 +205,42 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
 /* Bind (pool, layer) as this thread's cache for nvk_paged_attention; pool NULL unbinds.
  * ref: the layer slicing in LlamaModel::attention, include/core/model.hpp:400-403. */
 int nvk_bind_pool(nvk_pool *pool, int layer);
+
+/* ------------------------------------------------------------ decode batch --
+ * Per-request block tables kept on the device, and one append + attention call
+ * per layer for all DECODING requests.
+ * ref: ScheduledBatch::decode_requests  include/scheduler/scheduler.hpp:24-43,66-77 (formed, never executed:
+ *      include/scheduler/batched_runner.hpp:84-85), Request::block_ids include/scheduler/request.hpp:74,
+ *      the per-request allocator API include/scheduler/block_manager.hpp:145-171, and the per-token
+ *      bookkeeping of LlamaModel::forward include/core/model.hpp:181-207,221 applied per request.
+ * A block id names the same slot in every layer's slab, so one table and one plan serve all layers of a
+ * step.  Not thread-safe; one batch per pool stream.  Step protocol:
+ *   nvk_batch_begin_step(ids)      every listed request takes one token: a block is drawn for those at a
+ *                                  block boundary (NVK_ERR_OOM, text "Out of memory: no free blocks", with
+ *                                  nothing changed when the pool cannot cover them); tables, positions and
+ *                                  context lengths of the step reach HBM (new entries only when the list is
+ *                                  the previous step's); the decode plan is built.  Asynchronous on `stream`.
+ *   nvk_batch_layer(layer, ...)    q [n, n_heads, hd] (rotated in place when rope_theta > 0), k_rows/v_rows
+ *                                  [n, n_kv_heads*hd], out [n, n_heads, hd], all device pointers in the
+ *                                  order of the step's list: RoPE + append, then attention over pos+1 tokens.
+ *   nvk_batch_end_step()           lengths advance by one.
+ * nvk_batch_finish_request waits for the device, returns the request's blocks to the manager
+ * (BlockManager::free_request) and frees its slot. */
+typedef struct nvk_batch nvk_batch;
+int nvk_batch_create(nvk_pool *pool, nvk_block_manager *bm, int max_seqs, int max_blocks_per_seq,
+                     nvk_batch **out_batch);
+int nvk_batch_destroy(nvk_batch *batch);
+int nvk_batch_add_request(nvk_batch *batch, int request_id);
+int nvk_batch_finish_request(nvk_batch *batch, int request_id);
+int nvk_batch_num_requests(const nvk_batch *batch);
+int nvk_batch_request_len(const nvk_batch *batch, int request_id);                       /* tokens in the pool */
+int nvk_batch_request_blocks(const nvk_batch *batch, int request_id, int *ids, int cap); /* count; = block_ids */
+int nvk_batch_begin_step(nvk_batch *batch, const int *request_ids, int n, int n_heads, void *stream);
+int nvk_batch_layer(nvk_batch *batch, int layer, float *q_dev, const float *k_rows_dev, const float *v_rows_dev,
+                    float *out_dev, float rope_theta, void *stream);
+int nvk_batch_end_step(nvk_batch *batch);
+/* out2 = {steps that uploaded whole tables, steps that only patched new entries} */
+int nvk_batch_stats(const nvk_batch *batch, long long *out2);
 
 /* ---------------------------------------------------------- BlockManager --
  * Host-side allocator returning the same ids in the same order as

@@ -9,10 +9,11 @@ hyphen is not importable in Python.)
 from . import _capi
 from ._capi import NvkError, device_count, version
 from .attention import AUTO, SINGLE_PASS, SPLIT_K, DecodePlan, bind_pool, decode, decode_bench, decode_device, paged_attention, standard_attention
+from .batch import DecodeBatch
 from .block_manager import BlockManager
 from .kv_pool import PagedKVPool
 
 __all__ = [
-    "AUTO", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodePlan", "NvkError", "PagedKVPool", "bind_pool", "decode",
+    "AUTO", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "NvkError", "PagedKVPool", "bind_pool", "decode",
     "decode_bench", "decode_device", "device_count", "paged_attention", "standard_attention", "version",
 ]

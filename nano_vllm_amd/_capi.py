@@ -87,6 +87,17 @@ SIGNATURES = {
     "nvk_paged_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nvk_standard_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nvk_bind_pool": (C.c_int, [_vp, C.c_int]),
+    "nvk_batch_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "nvk_batch_destroy": (C.c_int, [_vp]),
+    "nvk_batch_add_request": (C.c_int, [_vp, C.c_int]),
+    "nvk_batch_finish_request": (C.c_int, [_vp, C.c_int]),
+    "nvk_batch_num_requests": (C.c_int, [_vp]),
+    "nvk_batch_request_len": (C.c_int, [_vp, C.c_int]),
+    "nvk_batch_request_blocks": (C.c_int, [_vp, C.c_int, _i, C.c_int]),
+    "nvk_batch_begin_step": (C.c_int, [_vp, _i, C.c_int, C.c_int, _vp]),
+    "nvk_batch_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp]),
+    "nvk_batch_end_step": (C.c_int, [_vp]),
+    "nvk_batch_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
     "nvk_bm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "nvk_bm_destroy": (None, [_vp]),
     "nvk_bm_allocate_block": (C.c_int, [_vp]),

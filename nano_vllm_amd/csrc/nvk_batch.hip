@@ -1,0 +1,420 @@
+// nvk_batch.hip -- the decode batch: per-request block tables kept on the device
+// and one append + attention call per layer for every DECODING request
+// (SURVEY.md 8f row f2).
+//
+// The reference's scheduler already forms ScheduledBatch::decode_requests
+// (include/scheduler/scheduler.hpp:24-43,66-77) and Request carries block_ids
+// (include/scheduler/request.hpp:74), but nothing executes them
+// (include/scheduler/batched_runner.hpp:84-85): every request runs alone through
+// LlamaModel::forward, whose block tables belong to the model, not to the request
+// (include/core/model.hpp:113,181-187).  This object is the missing piece: it owns,
+// per running request, the block list the per-request BlockManager API hands out
+// (include/scheduler/block_manager.hpp:145-171), mirrors the step's tables,
+// positions and context lengths in HBM, and drives the kernels of
+// nvk_paged_attn.hip through the public C ABI only.
+//
+// One block id names the same slot in every layer's slab (tables are shared by the
+// layers of a step, which is what lets one decode plan serve all of them); the
+// reference's model instead draws a separate block per layer from the shared list.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
+#include "nvk_internal.h"
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return nvk::fail(e__ == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "%s failed: %s (%s:%d)", #expr,  \
+                             hipGetErrorString(e__), __FILE__, __LINE__);                                              \
+    } while (0)
+
+namespace {
+
+// Same request list as the previous step: every sequence moves on by one token and the
+// freshly allocated blocks (row, column, id) are written into the resident tables.
+__global__ void nvk_batch_advance_kernel(int *__restrict__ tables, int max_blocks, int *__restrict__ positions,
+                                         int *__restrict__ ctx_lens, int n, const int *__restrict__ patches,
+                                         int n_patches)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        positions[i] += 1;
+        ctx_lens[i] += 1;
+    }
+    if (i < n_patches)
+        tables[(int64_t)patches[3 * i] * max_blocks + patches[3 * i + 1]] = patches[3 * i + 2];
+}
+
+struct Slot
+{
+    int              request_id = -1;
+    int              len        = 0; // tokens whose K/V are in the pool
+    std::vector<int> blocks;         // = Request::block_ids
+};
+
+struct DeviceScope
+{
+    int previous = -1;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&previous) != hipSuccess)
+            previous = -1;
+        (void)hipSetDevice(device);
+    }
+    ~DeviceScope()
+    {
+        if (previous >= 0)
+            (void)hipSetDevice(previous);
+    }
+};
+
+} // namespace
+
+struct nvk_batch
+{
+    nvk_pool          *pool = nullptr;
+    nvk_block_manager *bm   = nullptr;
+    int                max_seqs = 0, max_blocks = 0;
+    int                block_size = 0, device = 0;
+
+    std::vector<Slot>            slots; // dense; a finished request's slot is taken by the last one
+    std::unordered_map<int, int> slot_of;
+
+    // the step in flight
+    bool             in_step = false;
+    int              n_heads = 0;
+    std::vector<int> step_ids, resident_ids; // resident_ids: the list whose tables/positions are in HBM now
+    bool             resident_valid = false;
+
+    // pinned host staging and its device mirrors
+    int *h_tables = nullptr, *h_pos = nullptr, *h_ctx = nullptr, *h_patches = nullptr;
+    int *d_tables = nullptr, *d_pos = nullptr, *d_ctx = nullptr, *d_patches = nullptr;
+    hipEvent_t staged = nullptr; // the last copies out of the pinned buffers have finished
+    nvk_plan  *plan   = nullptr;
+
+    // counters for tests and tuning: how the tables reached the device
+    long long full_uploads = 0, patch_steps = 0;
+};
+
+namespace {
+
+hipStream_t stream_or_pool(nvk_batch *b, void *stream)
+{
+    if (stream)
+        return (hipStream_t)stream;
+    void *s = nullptr;
+    (void)nvk_pool_stream(b->pool, &s);
+    return (hipStream_t)s;
+}
+
+void release(nvk_batch *b)
+{
+    if (!b)
+        return;
+    DeviceScope scope(b->device);
+    (void)hipDeviceSynchronize();
+    if (b->plan)
+        (void)nvk_plan_destroy(b->plan);
+    for (int *p : {b->h_tables, b->h_pos, b->h_ctx, b->h_patches})
+        if (p)
+            (void)hipHostFree(p);
+    for (int *p : {b->d_tables, b->d_pos, b->d_ctx, b->d_patches})
+        if (p)
+            (void)hipFree(p);
+    if (b->staged)
+        (void)hipEventDestroy(b->staged);
+    delete b;
+}
+
+} // namespace
+
+extern "C" {
+
+int nvk_batch_create(nvk_pool *pool, nvk_block_manager *bm, int max_seqs, int max_blocks_per_seq, nvk_batch **out_batch)
+{
+    if (!out_batch)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_create: out_batch is null");
+    *out_batch = nullptr;
+    if (!pool || !bm || max_seqs <= 0 || max_blocks_per_seq <= 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_create: bad arguments");
+    int geo[6];
+    int rc = nvk_pool_geometry(pool, geo);
+    if (rc != NVK_OK)
+        return rc;
+    if (nvk_bm_block_size(bm) != geo[2] || nvk_bm_num_blocks(bm) > geo[1])
+        return nvk::fail(NVK_ERR_INVALID_ARG,
+                         "nvk_batch_create: block manager (%d blocks of %d) does not fit the pool (%d blocks of %d)",
+                         nvk_bm_num_blocks(bm), nvk_bm_block_size(bm), geo[1], geo[2]);
+    if ((long long)max_seqs * max_blocks_per_seq > 0x3fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_create: max_seqs x max_blocks_per_seq too large");
+
+    nvk_batch *b = new (std::nothrow) nvk_batch();
+    if (!b)
+        return nvk::fail(NVK_ERR_OOM, "nvk_batch_create: host allocation failed");
+    b->pool = pool, b->bm = bm, b->max_seqs = max_seqs, b->max_blocks = max_blocks_per_seq;
+    b->block_size = geo[2], b->device = geo[5];
+    DeviceScope  scope(b->device);
+    const size_t tab = (size_t)max_seqs * max_blocks_per_seq * sizeof(int);
+    const size_t vec = (size_t)max_seqs * sizeof(int);
+    hipError_t   e   = hipHostMalloc((void **)&b->h_tables, tab, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&b->h_pos, vec, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&b->h_ctx, vec, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&b->h_patches, 3 * vec, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->d_tables, tab);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->d_pos, vec);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->d_ctx, vec);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&b->d_patches, 3 * vec);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&b->staged, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipMemset(b->d_tables, 0, tab);
+    if (e != hipSuccess) {
+        const int code = nvk::fail(e == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "nvk_batch_create: %s",
+                                   hipGetErrorString(e));
+        release(b);
+        return code;
+    }
+    rc = nvk_plan_create(pool, &b->plan);
+    if (rc != NVK_OK) {
+        release(b);
+        return rc;
+    }
+    *out_batch = b;
+    return NVK_OK;
+}
+
+int nvk_batch_destroy(nvk_batch *batch)
+{
+    release(batch);
+    return NVK_OK;
+}
+
+int nvk_batch_add_request(nvk_batch *b, int request_id)
+{
+    if (!b)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_add_request: null batch");
+    if (b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_add_request: a step is in flight");
+    if (b->slot_of.count(request_id))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_add_request: request %d is already running", request_id);
+    if ((int)b->slots.size() >= b->max_seqs)
+        return nvk::fail(NVK_ERR_OOM, "nvk_batch_add_request: all %d sequence slots are taken", b->max_seqs);
+    Slot s;
+    s.request_id           = request_id;
+    b->slot_of[request_id] = (int)b->slots.size();
+    b->slots.push_back(std::move(s));
+    return NVK_OK;
+}
+
+int nvk_batch_finish_request(nvk_batch *b, int request_id)
+{
+    if (!b)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_finish_request: null batch");
+    if (b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_finish_request: a step is in flight");
+    auto it = b->slot_of.find(request_id);
+    if (it == b->slot_of.end())
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_finish_request: request %d is not running", request_id);
+    // Kernels of earlier steps may still be reading this request's blocks: they must be done
+    // before the ids can be handed to another request.
+    {
+        DeviceScope scope(b->device);
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    nvk_bm_free_request(b->bm, request_id); // ref: BlockManager::free_request, block_manager.hpp:157-171
+    const int slot = it->second;
+    b->slot_of.erase(it);
+    if (slot != (int)b->slots.size() - 1) {
+        b->slots[(size_t)slot]                    = std::move(b->slots.back());
+        b->slot_of[b->slots[(size_t)slot].request_id] = slot;
+    }
+    b->slots.pop_back();
+    b->resident_valid = false;
+    return NVK_OK;
+}
+
+int nvk_batch_num_requests(const nvk_batch *b) { return b ? (int)b->slots.size() : 0; }
+
+int nvk_batch_request_len(const nvk_batch *b, int request_id)
+{
+    if (!b)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_request_len: null batch");
+    auto it = b->slot_of.find(request_id);
+    if (it == b->slot_of.end())
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_request_len: request %d is not running", request_id);
+    return b->slots[(size_t)it->second].len;
+}
+
+int nvk_batch_request_blocks(const nvk_batch *b, int request_id, int *ids, int cap)
+{
+    if (!b || cap < 0 || (cap > 0 && !ids))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_request_blocks: bad arguments");
+    auto it = b->slot_of.find(request_id);
+    if (it == b->slot_of.end())
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_request_blocks: request %d is not running", request_id);
+    const std::vector<int> &v = b->slots[(size_t)it->second].blocks;
+    for (int i = 0; i < (int)v.size() && i < cap; i++)
+        ids[i] = v[(size_t)i];
+    return (int)v.size();
+}
+
+int nvk_batch_stats(const nvk_batch *b, long long *out2)
+{
+    if (!b || !out2)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_stats: null argument");
+    out2[0] = b->full_uploads, out2[1] = b->patch_steps;
+    return NVK_OK;
+}
+
+int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_heads, void *stream)
+{
+    if (!b || n < 0 || (n > 0 && !request_ids) || n_heads <= 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step: bad arguments");
+    if (b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step: the previous step was not ended");
+    if (n > b->max_seqs)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step: %d requests, %d slots", n, b->max_seqs);
+
+    // 1. validate the list and count the blocks this step needs (model.hpp:181: a new block when pos % block_size == 0)
+    std::vector<int> slot_idx((size_t)n);
+    int              need = 0;
+    {
+        std::unordered_map<int, int> seen;
+        for (int i = 0; i < n; i++) {
+            auto it = b->slot_of.find(request_ids[i]);
+            if (it == b->slot_of.end())
+                return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step: request %d is not running", request_ids[i]);
+            if (!seen.emplace(request_ids[i], i).second)
+                return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step: request %d listed twice", request_ids[i]);
+            slot_idx[(size_t)i] = it->second;
+            const Slot &s       = b->slots[(size_t)it->second];
+            if (s.len % b->block_size == 0) {
+                if (s.len / b->block_size >= b->max_blocks)
+                    return nvk::fail(NVK_ERR_INVALID_ARG,
+                                     "nvk_batch_begin_step: request %d is at %d tokens, its table holds %d blocks",
+                                     s.request_id, s.len, b->max_blocks);
+                need++;
+            }
+        }
+    }
+    if (need > nvk_bm_num_free_blocks(b->bm))
+        return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks (%d needed, %d free)", need,
+                         nvk_bm_num_free_blocks(b->bm)); // the reference's text, model.hpp:184
+
+    DeviceScope scope(b->device);
+    hipStream_t st = stream_or_pool(b, stream);
+    HIP_TRY(hipEventSynchronize(b->staged)); // the pinned buffers are ours again
+
+    // 2. allocate, in list order, through the per-request API (block_manager.hpp:145-154)
+    const bool same_list = b->resident_valid && (int)b->resident_ids.size() == n
+                           && std::equal(request_ids, request_ids + n, b->resident_ids.begin());
+    int n_patches = 0, max_ctx = 0;
+    for (int i = 0; i < n; i++) {
+        Slot &s = b->slots[(size_t)slot_idx[(size_t)i]];
+        if (s.len % b->block_size == 0) {
+            const int id = nvk_bm_allocate_block_for_request(b->bm, s.request_id);
+            if (id < 0) { // another thread took blocks between the check and here: undo this step's allocations
+                for (int k = 0; k < n_patches; k++) {
+                    Slot &u = b->slots[(size_t)slot_idx[(size_t)b->h_patches[3 * k]]];
+                    nvk_bm_free_block_safe(b->bm, u.blocks.back());
+                    u.blocks.pop_back();
+                }
+                b->resident_valid = false;
+                return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks");
+            }
+            b->h_patches[3 * n_patches]     = i;
+            b->h_patches[3 * n_patches + 1] = s.len / b->block_size;
+            b->h_patches[3 * n_patches + 2] = id;
+            n_patches++;
+            s.blocks.push_back(id);
+        }
+        max_ctx = std::max(max_ctx, s.len + 1);
+    }
+
+    // 3. bring the step's tables / positions / context lengths to the device
+    if (n > 0) {
+        if (same_list) {
+            if (n_patches > 0)
+                HIP_TRY(hipMemcpyAsync(b->d_patches, b->h_patches, (size_t)3 * n_patches * sizeof(int),
+                                       hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(nvk_batch_advance_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b->d_tables,
+                               b->max_blocks, b->d_pos, b->d_ctx, n, b->d_patches, n_patches);
+            HIP_TRY(hipGetLastError());
+            b->patch_steps++;
+        }
+        else {
+            for (int i = 0; i < n; i++) {
+                const Slot &s   = b->slots[(size_t)slot_idx[(size_t)i]];
+                int        *row = b->h_tables + (size_t)i * b->max_blocks;
+                std::copy(s.blocks.begin(), s.blocks.end(), row);
+                std::fill(row + s.blocks.size(), row + b->max_blocks, 0);
+                b->h_pos[i] = s.len;
+                b->h_ctx[i] = s.len + 1;
+            }
+            HIP_TRY(hipMemcpyAsync(b->d_tables, b->h_tables, (size_t)n * b->max_blocks * sizeof(int),
+                                   hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(b->d_pos, b->h_pos, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(b->d_ctx, b->h_ctx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+            b->full_uploads++;
+        }
+        HIP_TRY(hipEventRecord(b->staged, st));
+    }
+    b->step_ids.assign(request_ids, request_ids + n);
+    b->resident_ids   = b->step_ids;
+    b->resident_valid = n > 0;
+
+    // 4. one plan for all the layers of this step
+    int rc = nvk_plan_build(b->plan, n, n_heads, b->d_ctx, max_ctx, NVK_DECODE_AUTO, 0, (void *)st);
+    if (rc != NVK_OK) {
+        b->resident_valid = false;
+        return rc;
+    }
+    b->n_heads = n_heads;
+    b->in_step = true;
+    return NVK_OK;
+}
+
+int nvk_batch_layer(nvk_batch *b, int layer, float *q_dev, const float *k_rows_dev, const float *v_rows_dev,
+                    float *out_dev, float rope_theta, void *stream)
+{
+    if (!b || !b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_layer: no step in flight (call nvk_batch_begin_step)");
+    const int n = (int)b->step_ids.size();
+    if (n == 0)
+        return NVK_OK;
+    if (!q_dev || !k_rows_dev || !v_rows_dev || !out_dev || rope_theta < 0.f)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_layer: bad arguments");
+    DeviceScope scope(b->device);
+    hipStream_t st = stream_or_pool(b, stream);
+    // KV append for every sequence of the step (model.hpp:190-207), with the rotation of model.hpp:169-175 when asked
+    int rc = nvk_pool_rope_append_batch(b->pool, layer, n, b->n_heads, q_dev, k_rows_dev, v_rows_dev, b->d_tables,
+                                        b->max_blocks, b->d_pos, rope_theta, NVK_PTR_DEVICE, (void *)st);
+    if (rc != NVK_OK)
+        return rc;
+    // attention over pos + 1 tokens: the new token attends to itself (model.hpp:221, :397)
+    return nvk_decode_planned(b->pool, layer, b->plan, q_dev, b->d_tables, b->max_blocks, out_dev, (void *)st);
+}
+
+int nvk_batch_end_step(nvk_batch *b)
+{
+    if (!b || !b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_end_step: no step in flight");
+    for (int id : b->step_ids)
+        b->slots[(size_t)b->slot_of[id]].len += 1;
+    b->in_step = false;
+    return NVK_OK;
+}
+
+} // extern "C"

@@ -626,20 +626,27 @@ __global__ void __launch_bounds__(256)
     const int pos = positions[seq];
     if (pos < 0)
         return;
-    const int half = head_dim >> 1;
+    const int  half   = head_dim >> 1;
+    const bool rotate_on = inv_freq != nullptr; // null: plain append, q untouched, K copied as it is
     for (int p = threadIdx.x; p < half; p += blockDim.x) {
-        const float  angle = (float)pos * inv_freq[p];
-        double       sn, cs;
-        sincos((double)angle, &sn, &cs);
-        s_cs[p] = make_float2((float)cs, (float)sn);
+        float2 cs = make_float2(1.f, 0.f);
+        if (rotate_on) {
+            const float angle = (float)pos * inv_freq[p];
+            double      sn, c;
+            sincos((double)angle, &sn, &c);
+            cs = make_float2((float)c, (float)sn);
+        }
+        s_cs[p] = cs;
     }
     __syncthreads();
 
     auto rotate = [](float2 v, float2 cs) { return rope_rotate(v, cs); };
 
-    float2 *q2 = reinterpret_cast<float2 *>(q + (int64_t)seq * n_heads * head_dim);
-    for (int i = threadIdx.x; i < n_heads * half; i += blockDim.x)
-        q2[i] = rotate(q2[i], s_cs[i % half]);
+    if (rotate_on) {
+        float2 *q2 = reinterpret_cast<float2 *>(q + (int64_t)seq * n_heads * head_dim);
+        for (int i = threadIdx.x; i < n_heads * half; i += blockDim.x)
+            q2[i] = rotate(q2[i], s_cs[i % half]);
+    }
 
     const int     row_len = n_kv_heads * head_dim;
     const int     blk     = token_block(pos, bs_magic);
@@ -649,7 +656,7 @@ __global__ void __launch_bounds__(256)
     const float2 *k2      = reinterpret_cast<const float2 *>(k_rows + (int64_t)seq * row_len);
     float2       *kd      = reinterpret_cast<float2 *>(k_layer + at);
     for (int i = threadIdx.x; i < n_kv_heads * half; i += blockDim.x)
-        kd[i] = rotate(k2[i], s_cs[i % half]);
+        kd[i] = rotate_on ? rotate(k2[i], s_cs[i % half]) : k2[i];
     for (int i = threadIdx.x * 4; i < row_len; i += blockDim.x * 4)
         *reinterpret_cast<float4 *>(v_layer + at + i) =
             *reinterpret_cast<const float4 *>(v_rows + (int64_t)seq * row_len + i);

@@ -711,8 +711,9 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
     int rc = check_pool_layer(pool, layer, "nvk_pool_rope_append_batch");
     if (rc != NVK_OK)
         return rc;
-    if (num_seqs < 0 || max_blocks <= 0 || n_heads <= 0 || !(rope_theta > 0.f)
-        || (num_seqs > 0 && (!q || !k_rows || !v_rows || !block_tables || !positions)))
+    const bool rotate = rope_theta > 0.f; // 0: plain append (q may be null and is not touched)
+    if (num_seqs < 0 || max_blocks <= 0 || n_heads <= 0 || !(rope_theta >= 0.f)
+        || (num_seqs > 0 && ((rotate && !q) || !k_rows || !v_rows || !block_tables || !positions)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: bad arguments");
     if (pool->head_dim % 2 != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: head_dim must be even");
@@ -725,7 +726,7 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
 
     // inv_freq[p] = 1 / powf(theta, 2p / head_dim): the reference's own expression (positional.hpp:16)
     // through the host libm, rebuilt only when theta changes
-    if (!pool->rope_inv_freq || pool->rope_theta != rope_theta) {
+    if (rotate && (!pool->rope_inv_freq || pool->rope_theta != rope_theta)) {
         std::vector<float> freq((size_t)half);
         for (int i = 0; i < hd; i += 2)
             freq[(size_t)(i / 2)] = 1.0f / powf(rope_theta, (float)i / hd);
@@ -765,7 +766,8 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
         dv         = (const float *)(base + al(q_b) + al(rows_b));
         dt         = (const int *)(base + al(q_b) + 2 * al(rows_b));
         dp         = (const int *)(base + al(q_b) + 2 * al(rows_b) + al(tab_b));
-        HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, st));
+        if (rotate)
+            HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync((void *)dk, k_rows, rows_b, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync((void *)dv, v_rows, rows_b, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync((void *)dt, block_tables, tab_b, hipMemcpyHostToDevice, st));
@@ -775,11 +777,13 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: ptr_kind %d", ptr_kind);
     }
     hipLaunchKernelGGL(nvk::nvk_rope_append_kernel, dim3((unsigned)num_seqs), dim3(256), (size_t)half * sizeof(float2), st,
-                       pool->k_layer(layer), pool->v_layer(layer), dq, dk, dv, dt, max_blocks, dp, pool->rope_inv_freq,
+                       pool->k_layer(layer), pool->v_layer(layer), dq, dk, dv, dt, max_blocks, dp,
+                       rotate ? pool->rope_inv_freq : (const float *)nullptr,
                        pool->num_blocks, pool->block_size, pool->bs_magic, n_heads, pool->n_kv_heads, hd);
     HIP_TRY(hipGetLastError());
     if (ptr_kind == NVK_PTR_HOST) {
-        HIP_TRY(hipMemcpyAsync(q, dq, q_b, hipMemcpyDeviceToHost, st));
+        if (rotate)
+            HIP_TRY(hipMemcpyAsync(q, dq, q_b, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     return NVK_OK;

@@ -1,0 +1,144 @@
+"""the decode batch (nvk_batch_*) under a continuous-batching schedule.
+
+Requests join and finish at different steps; every step runs RoPE + append + attention for all running
+requests, layer by layer.  Checked per request against the CPU checker's own rope -> append ->
+paged_attention on a host pool (parity for a batch is defined per sequence, SURVEY.md TL;DR), and the
+block ids against the checker's restatement of the reference's per-request BlockManager API."""
+import numpy as np
+import pytest
+
+import nano_vllm_amd as nv
+import oracle_lib as ol
+from golden_defs import BmCLib
+from hipmem import DeviceArray
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-4, 1e-5
+
+
+def close(got, want):
+    return bool((np.abs(got - want) <= ATOL + RTOL * np.abs(want)).all())
+
+
+def test_continuous_batching_schedule():
+    L, H, KV, hd, bs = 2, 8, 2, 64, 8
+    nb, max_seqs, max_blocks = 48, 6, 8
+    theta = 10000.0
+    rng = np.random.default_rng(21)
+    # request id -> (step it joins, tokens it will take)
+    plan = {10: (0, 30), 11: (0, 9), 12: (3, 17), 13: (5, 40), 14: (12, 8), 15: (12, 25), 16: (20, 12)}
+    host_k = np.zeros((L, nb, bs, KV, hd), np.float32)
+    host_v = np.zeros_like(host_k)
+    ref_bm = BmCLib(ol.ORACLE, "oracle_", nb, bs)
+    lens, running = {}, []
+    bm = nv.BlockManager(nb, bs)
+    with nv.PagedKVPool(L, nb, bs, KV, hd) as pool, nv.DecodeBatch(pool, bm, max_seqs, max_blocks) as batch:
+        step = 0
+        while step < 70 and (running or any(j >= step for j, _ in plan.values())):
+            for rid, (join, _) in plan.items():
+                if join == step:
+                    batch.add_request(rid)
+                    running.append(rid)
+                    lens[rid] = 0
+            ids = list(running)  # ScheduledBatch.decode_requests: the running requests, in admission order
+            if ids:
+                batch.begin_step(ids, H)
+                # the same allocations, in the same order, through the reference-equivalent allocator
+                for rid in ids:
+                    if lens[rid] % bs == 0:
+                        ref_bm.do(["req_alloc_block", rid])
+                for rid in ids:
+                    assert batch.request_blocks(rid) == ref_bm.do(["req_blocks", rid]), (step, rid)
+                n = len(ids)
+                for layer in range(L):
+                    q = rng.standard_normal((n, H, hd), dtype=np.float32)
+                    k = rng.standard_normal((n, KV, hd), dtype=np.float32)
+                    v = rng.standard_normal((n, KV, hd), dtype=np.float32)
+                    qd, kd, vd = DeviceArray(q), DeviceArray(k), DeviceArray(v)
+                    outd = DeviceArray(np.full_like(q, np.nan))
+                    batch.layer(layer, qd, kd, vd, outd, theta)
+                    pool.synchronize()
+                    got, q_rot = outd.numpy(), qd.numpy()
+                    for i, rid in enumerate(ids):
+                        pos = lens[rid]
+                        table = np.asarray(batch.request_blocks(rid), np.int32)
+                        wq, wk = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q[i], k[i], pos, hd, H, KV, theta)
+                        host_k[layer, table[pos // bs], pos % bs] = wk
+                        host_v[layer, table[pos // bs], pos % bs] = v[i]
+                        want = ol.oracle_paged_attention(wq, host_k[layer], host_v[layer], table, pos + 1, bs, hd, H, KV)
+                        assert close(q_rot[i], wq), (step, layer, rid)
+                        assert close(got[i], want), (step, layer, rid, float(np.abs(got[i] - want).max()))
+                batch.end_step()
+                for rid in ids:
+                    lens[rid] += 1
+                    assert batch.request_len(rid) == lens[rid]
+            for rid in list(running):
+                if lens[rid] >= plan[rid][1]:
+                    batch.finish_request(rid)
+                    ref_bm.do(["req_free", rid])
+                    running.remove(rid)
+            assert bm.get_num_free_blocks() == ref_bm.do(["num_free"])
+            step += 1
+        assert not running and batch.num_requests() == 0
+        assert bm.get_num_free_blocks() == nb  # every block came back
+        st = batch.stats()
+        assert st["patch_steps"] > 20 and 5 <= st["full_uploads"] <= 16, st  # tables re-sent only when the list changes
+    ref_bm.close()
+
+
+def test_out_of_blocks_leaves_the_batch_unchanged():
+    L, H, KV, hd, bs = 1, 4, 2, 32, 4
+    bm = nv.BlockManager(3, bs)
+    with nv.PagedKVPool(L, 3, bs, KV, hd) as pool, nv.DecodeBatch(pool, bm, 4, 4) as batch:
+        for rid in (1, 2, 3, 4):
+            batch.add_request(rid)
+        with pytest.raises(nv.NvkError) as e:  # four requests at pos 0 need four blocks, three exist
+            batch.begin_step([1, 2, 3, 4], H)
+        assert e.value.code == nv._capi.ERR_OOM and "Out of memory: no free blocks" in e.value.message
+        assert bm.get_num_free_blocks() == 3 and all(batch.request_blocks(r) == [] for r in (1, 2, 3, 4))
+        batch.begin_step([1, 2, 3], H)
+        with pytest.raises(nv.NvkError):  # a step is in flight
+            batch.begin_step([1], H)
+        with pytest.raises(nv.NvkError):
+            batch.finish_request(1)
+        batch.end_step()
+        assert [batch.request_blocks(r) for r in (1, 2, 3)] == [[0], [1], [2]]
+        with pytest.raises(nv.NvkError):
+            batch.begin_step([1, 1], H)  # listed twice
+        with pytest.raises(nv.NvkError):
+            batch.begin_step([9], H)  # not running
+        with pytest.raises(nv.NvkError):
+            batch.add_request(2)  # already running
+        batch.finish_request(2)
+        batch.begin_step([4], H)  # request 4 gets request 2's block back: lowest free id first
+        batch.end_step()
+        assert batch.request_blocks(4) == [1]
+
+
+def test_plain_append_mode_matches_append_batch():
+    """rope_theta = 0: nvk_batch_layer appends K as it is and leaves q alone."""
+    L, H, KV, hd, bs = 1, 4, 2, 32, 4
+    rng = np.random.default_rng(3)
+    bm = nv.BlockManager(16, bs)
+    with nv.PagedKVPool(L, 16, bs, KV, hd) as pool, nv.DecodeBatch(pool, bm, 3, 4) as batch:
+        for rid in (5, 6, 7):
+            batch.add_request(rid)
+        hk = np.zeros((16, bs, KV, hd), np.float32)
+        hv = np.zeros_like(hk)
+        for t in range(10):
+            batch.begin_step([5, 6, 7], H)
+            q = rng.standard_normal((3, H, hd), dtype=np.float32)
+            k = rng.standard_normal((3, KV, hd), dtype=np.float32)
+            v = rng.standard_normal((3, KV, hd), dtype=np.float32)
+            qd, outd = DeviceArray(q), DeviceArray(np.empty_like(q))
+            batch.layer(0, qd, DeviceArray(k), DeviceArray(v), outd, 0.0)
+            pool.synchronize()
+            assert np.array_equal(qd.numpy(), q)
+            got = outd.numpy()
+            for i, rid in enumerate((5, 6, 7)):
+                table = np.asarray(batch.request_blocks(rid), np.int32)
+                hk[table[t // bs], t % bs], hv[table[t // bs], t % bs] = k[i], v[i]
+                want = ol.oracle_paged_attention(q[i], hk, hv, table, t + 1, bs, hd, H, KV)
+                assert close(got[i], want), (t, rid)
+            batch.end_step()
