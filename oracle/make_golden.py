@@ -10,6 +10,7 @@ outputs; the fixtures are data only (no reference source in any form).
   F1  tests/golden/block_manager_traces.json   BlockManager op traces -> results
   F2  tests/golden/attention_cases.npz         single-sequence paged_attention outputs
   F3  (same file) standard_attention outputs on the same rows (paged == contiguous)
+  F6  tests/golden/prefill_cases.npz           chunked_attention outputs (experimental/chunked_prefill)
   F4  tests/golden/tiny_llama_stream.npz       synthetic llama2.c checkpoint: token stream,
                                                logits, attention outputs, F5 block tables
 
@@ -30,8 +31,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as ol  # noqa: E402
-from golden_defs import (ATTENTION_CASES, TINY_MODELS, BmCLib, attention_case_inputs, bm_trace_script,  # noqa: E402
-                         replay, write_checkpoint)
+from golden_defs import (ATTENTION_CASES, PREFILL_CASES, TINY_MODELS, BmCLib, attention_case_inputs,  # noqa: E402
+                         bm_trace_script, prefill_case_inputs, replay, write_checkpoint)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -76,6 +77,14 @@ def main():
             assert np.array_equal(std, out), name  # the reference's own structural identity
     np.savez_compressed(os.path.join(GOLD, "attention_cases.npz"), **store)
     print(f"F2/F3: {len(ATTENTION_CASES)} attention cases")
+
+    # ---- F6: chunked-prefill attention (experimental/chunked_prefill) -------------
+    store = {}
+    for case in PREFILL_CASES:
+        q, k_lin, v_lin = prefill_case_inputs(case)
+        store[case["name"] + "/out"] = ol.ref_chunked_attention(q, k_lin, v_lin, case["start_pos"], case["n_kv_heads"])
+    np.savez_compressed(os.path.join(GOLD, "prefill_cases.npz"), **store)
+    print(f"F6: {len(PREFILL_CASES)} chunked-prefill cases")
 
     # ---- F4 / F5 ---------------------------------------------------------------
     store = {}

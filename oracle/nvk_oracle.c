@@ -157,6 +157,69 @@ void oracle_standard_attention(float *out, const float *q, const float *key_cach
     }
 }
 
+/* Restates LlamaModelChunked::chunked_attention,
+ * experimental/chunked_prefill/model_chunked.hpp:167-224: causal attention of a chunk of
+ * chunk_size query tokens at positions start_pos + b over one layer's contiguous
+ * [max_seq_len, n_kv_heads, head_dim] cache; query b attends to t <= start_pos + b (:186).
+ * Scratch att is [chunk_size, n_heads, max_seq_len] (:183).  Same loops as the decode
+ * attention per query, so row b equals oracle_standard_attention(pos = start_pos + b). */
+void oracle_chunked_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
+                              float *att, int chunk_size, int start_pos, int head_dim, int n_heads, int n_kv_heads,
+                              int max_seq_len)
+{
+    const int     kv_mul  = n_heads / n_kv_heads;
+    const float   scale   = 1.0f / sqrtf((float)head_dim);
+    const int64_t row_len = (int64_t)n_kv_heads * head_dim;
+    memset(out, 0, (size_t)chunk_size * n_heads * head_dim * sizeof(float)); /* :176 */
+    for (int b = 0; b < chunk_size; b++) {
+        const int curr = start_pos + b;
+        for (int h = 0; h < n_heads; h++) {
+            const float  *qh   = q + ((int64_t)b * n_heads + h) * head_dim;
+            float        *w    = att + ((int64_t)b * n_heads + h) * max_seq_len;
+            const int64_t at_h = (int64_t)(h / kv_mul) * head_dim;
+            for (int t = 0; t <= curr; t++) {
+                const float *kv  = key_cache + (int64_t)t * row_len + at_h;
+                float        acc = 0.0f;
+                for (int i = 0; i < head_dim; i++)
+                    acc += qh[i] * kv[i];
+                acc *= scale;
+                w[t] = acc;
+            }
+            float top = -1e10f;
+            for (int t = 0; t <= curr; t++)
+                if (w[t] > top)
+                    top = w[t];
+            float denom = 0.0f;
+            for (int t = 0; t <= curr; t++) {
+                w[t] = expf(w[t] - top);
+                denom += w[t];
+            }
+            for (int t = 0; t <= curr; t++)
+                w[t] /= denom;
+            float *oh = out + ((int64_t)b * n_heads + h) * head_dim;
+            for (int t = 0; t <= curr; t++) {
+                const float *vv = value_cache + (int64_t)t * row_len + at_h;
+                const float  p  = w[t];
+                for (int i = 0; i < head_dim; i++)
+                    oh[i] += p * vv[i];
+            }
+        }
+    }
+}
+
+/* The paged form of the same thing (ours: the reference's chunked prefill only knows the
+ * contiguous cache): query b of the chunk is Attention::paged_attention with
+ * num_tokens = start_pos + b + 1 over the sequence's block table. */
+void oracle_paged_prefill_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
+                                    const int *block_table, float *att_scores, int chunk_size, int start_pos,
+                                    int block_size, int head_dim, int n_heads, int n_kv_heads)
+{
+    for (int b = 0; b < chunk_size; b++)
+        oracle_paged_attention(out + (int64_t)b * n_heads * head_dim, q + (int64_t)b * n_heads * head_dim, key_cache,
+                               value_cache, block_table, att_scores, start_pos + b + 1, block_size, head_dim, n_heads,
+                               n_kv_heads);
+}
+
 /* Batched decode = the reference function once per sequence (SURVEY.md TL;DR:
  * the reference has no batched decode; parity for a batch is defined per
  * sequence).  block_tables is row-padded [num_seqs, max_blocks]. */

@@ -16,6 +16,7 @@
 //   LlamaModel                      include/core/model.hpp:104-433
 //   Sampler (greedy branch)         include/core/sampler.hpp:24-29
 //   Ops::apply_rope                 include/ops/positional.hpp:13-39
+//   LlamaModelChunked::chunked_attention  experimental/chunked_prefill/model_chunked.hpp:167-224
 
 #include <cstdio>
 #include <cstring>
@@ -25,10 +26,20 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
 #include "core/attention.hpp"
 #include "core/model.hpp"
 #include "core/sampler.hpp"
 #include "scheduler/block_manager.hpp"
+
+// LlamaModelChunked::chunked_attention is a private member (model_chunked.hpp:166-167); the shim
+// needs to call it on its own, so the access specifier is widened for this one include only.
+#define private public
+#include "experimental/chunked_prefill/model_chunked.hpp"
+#undef private
 
 namespace {
 
@@ -89,6 +100,26 @@ void ref_paged_attention_batch(float *out, const float *q, const float *key_cach
                                    key_cache, value_cache, block_tables + (size_t)s * max_blocks, att_scores,
                                    ctx_lens[s], block_size, head_dim, n_heads, n_kv_heads);
     }
+}
+
+// LlamaModelChunked::chunked_attention, experimental/chunked_prefill/model_chunked.hpp:167-224, on a
+// one-layer contiguous cache [max_seq_len, n_kv_heads, head_dim]; q/out are [chunk_size, n_heads, head_dim].
+void ref_chunked_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
+                           int chunk_size, int start_pos, int head_dim, int n_heads, int n_kv_heads, int max_seq_len)
+{
+    LlamaModelChunked m;
+    m.config.n_layers    = 1;
+    m.config.n_heads     = n_heads;
+    m.config.n_kv_heads  = n_kv_heads;
+    m.config.head_dim    = head_dim;
+    m.config.dim         = n_heads * head_dim;
+    m.config.max_seq_len = max_seq_len;
+    const size_t cache   = (size_t)max_seq_len * n_kv_heads * head_dim;
+    m.state.key_cache.assign(key_cache, key_cache + cache);
+    m.state.value_cache.assign(value_cache, value_cache + cache);
+    m.chunk_state.q_batch.assign(q, q + (size_t)chunk_size * n_heads * head_dim);
+    m.chunk_state.att_batch.resize((size_t)chunk_size * n_heads * max_seq_len);
+    m.chunked_attention(0, chunk_size, start_pos, out);
 }
 
 // Ops::apply_rope, include/ops/positional.hpp:13-39 (reached through core/model.hpp)

@@ -58,6 +58,40 @@ def attention_case_inputs(case):
     return q, k_pool, v_pool, table
 
 
+# ------------------------------------------------------------------ F6 cases
+# chunked-prefill attention: (n_heads, n_kv_heads, head_dim, start_pos, chunk_size)
+PREFILL_CASES = []
+for _i, (_H, _KV, _hd, _start, _C) in enumerate([(6, 6, 48, 0, 37), (6, 6, 48, 40, 16), (32, 8, 128, 0, 64),
+                                                  (32, 8, 128, 100, 33), (8, 2, 64, 7, 70), (4, 4, 32, 0, 1),
+                                                  (16, 1, 128, 31, 34), (12, 3, 64, 64, 64)]):
+    PREFILL_CASES.append({"name": f"h{_H}_kv{_KV}_d{_hd}_s{_start}_c{_C}", "index": _i, "n_heads": _H,
+                          "n_kv_heads": _KV, "head_dim": _hd, "start_pos": _start, "chunk_size": _C})
+
+
+def prefill_case_inputs(case):
+    """q [C, H, hd] and the contiguous cache rows k_lin/v_lin [start+C, KV, hd] of a chunked-prefill case."""
+    i, H, KV, hd = case["index"], case["n_heads"], case["n_kv_heads"], case["head_dim"]
+    T = case["start_pos"] + case["chunk_size"]
+    q = uniform(6000 + i, 0, case["chunk_size"] * H * hd).reshape(case["chunk_size"], H, hd)
+    k_lin = uniform(6100 + i, 0, T * KV * hd).reshape(T, KV, hd)
+    v_lin = uniform(6200 + i, 0, T * KV * hd).reshape(T, KV, hd)
+    return q, k_lin, v_lin
+
+
+def paged_from_contiguous(k_lin, v_lin, block_size, seed, spare=3):
+    """The same rows behind a shuffled block table: returns (k_pool, v_pool, table)."""
+    T, KV, hd = k_lin.shape
+    need = (T + block_size - 1) // block_size
+    nb = need + spare
+    table = shuffled_permutation(nb, seed)[:max(need, 1)].astype(np.int32)
+    k_pool = np.zeros((nb, block_size, KV, hd), np.float32)
+    v_pool = np.zeros_like(k_pool)
+    for t in range(T):
+        k_pool[table[t // block_size], t % block_size] = k_lin[t]
+        v_pool[table[t // block_size], t % block_size] = v_lin[t]
+    return k_pool, v_pool, table
+
+
 # ------------------------------------------------------------ F1 BM scripts
 def bm_trace_script():
     scripts = []

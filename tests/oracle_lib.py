@@ -36,6 +36,10 @@ def _load_oracle(path):
     lib.oracle_paged_attention.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]
     lib.oracle_standard_attention.restype = None
     lib.oracle_standard_attention.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]
+    lib.oracle_chunked_attention.restype = None
+    lib.oracle_chunked_attention.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]
+    lib.oracle_paged_prefill_attention.restype = None
+    lib.oracle_paged_prefill_attention.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]
     lib.oracle_decode_batch.restype = _i
     lib.oracle_decode_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i]
     lib.oracle_apply_rope.restype = None
@@ -92,6 +96,9 @@ def _load_ref(path):
     lib.ref_standard_attention.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]
     lib.ref_paged_attention_batch.restype = None
     lib.ref_paged_attention_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i]
+    if hasattr(lib, "ref_chunked_attention"):
+        lib.ref_chunked_attention.restype = None
+        lib.ref_chunked_attention.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]
     if hasattr(lib, "ref_apply_rope"):
         lib.ref_apply_rope.restype = None
         lib.ref_apply_rope.argtypes = [_vp, _vp, _i, _i, _i, _i, C.c_float]
@@ -216,3 +223,42 @@ def apply_rope(lib_fn, q, k, pos, head_dim, n_heads, n_kv_heads, theta=10000.0):
     k = np.array(k, np.float32, copy=True).reshape(n_kv_heads, head_dim)
     lib_fn(_p(q), _p(k), int(pos), int(head_dim), int(n_heads), int(n_kv_heads), C.c_float(theta))
     return q, k
+
+
+def oracle_chunked_attention(q, k_lin, v_lin, start_pos, n_kv_heads):
+    """q [C, H, hd] at positions start_pos + b over a contiguous cache [max_seq_len, KV, hd] -> out [C, H, hd]."""
+    q = np.ascontiguousarray(q, np.float32)
+    C_, H, hd = q.shape
+    k_lin = np.ascontiguousarray(k_lin, np.float32)
+    v_lin = np.ascontiguousarray(v_lin, np.float32)
+    max_seq = k_lin.shape[0]
+    out = np.full_like(q, np.nan)
+    att = np.empty(C_ * H * max_seq, np.float32)
+    ORACLE.oracle_chunked_attention(_p(out), _p(q), _p(k_lin), _p(v_lin), _p(att), C_, int(start_pos), hd, H,
+                                    int(n_kv_heads), max_seq)
+    return out
+
+
+def ref_chunked_attention(q, k_lin, v_lin, start_pos, n_kv_heads):
+    q = np.ascontiguousarray(q, np.float32)
+    C_, H, hd = q.shape
+    k_lin = np.ascontiguousarray(k_lin, np.float32)
+    v_lin = np.ascontiguousarray(v_lin, np.float32)
+    out = np.full_like(q, np.nan)
+    REF.ref_chunked_attention(_p(out), _p(q), _p(k_lin), _p(v_lin), C_, int(start_pos), hd, H, int(n_kv_heads),
+                              k_lin.shape[0])
+    return out
+
+
+def oracle_paged_prefill(q, k_cache, v_cache, table, start_pos, block_size, n_kv_heads):
+    """q [C, H, hd]: query b is paged_attention with num_tokens = start_pos + b + 1 over `table`."""
+    q = np.ascontiguousarray(q, np.float32)
+    C_, H, hd = q.shape
+    k_cache = np.ascontiguousarray(k_cache, np.float32)
+    v_cache = np.ascontiguousarray(v_cache, np.float32)
+    table = np.ascontiguousarray(table, np.int32)
+    out = np.full_like(q, np.nan)
+    att = np.empty(H * (start_pos + C_ + 1), np.float32)
+    ORACLE.oracle_paged_prefill_attention(_p(out), _p(q), _p(k_cache), _p(v_cache), _p(table), _p(att), C_,
+                                          int(start_pos), int(block_size), hd, H, int(n_kv_heads))
+    return out

@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from golden_defs import ATTENTION_CASES, TINY_MODELS, BmCLib, attention_case_inputs, replay, write_checkpoint
+from golden_defs import (ATTENTION_CASES, PREFILL_CASES, TINY_MODELS, BmCLib, attention_case_inputs,
+                         paged_from_contiguous, prefill_case_inputs, replay, write_checkpoint)
 
 pytestmark = pytest.mark.skipif(ol.ORACLE is None, reason="oracle/libnvk_oracle.so not built (make oracle)")
 
@@ -49,6 +50,18 @@ def test_attention_case_bit_exact(case, golden_dir):
         assert np.array_equal(std, out)
     else:
         assert not out.any()
+
+
+@pytest.mark.parametrize("case", PREFILL_CASES, ids=[c["name"] for c in PREFILL_CASES])
+def test_chunked_prefill_case_bit_exact(case, golden_dir):
+    """F6: the reference's chunked_attention (contiguous cache), and the paged form on the same rows."""
+    gold = np.load(os.path.join(golden_dir, "prefill_cases.npz"))[case["name"] + "/out"]
+    q, k_lin, v_lin = prefill_case_inputs(case)
+    out = ol.oracle_chunked_attention(q, k_lin, v_lin, case["start_pos"], case["n_kv_heads"])
+    assert np.array_equal(out.view(np.uint32), gold.view(np.uint32))
+    k_pool, v_pool, table = paged_from_contiguous(k_lin, v_lin, 16, 8000 + case["index"])
+    paged = ol.oracle_paged_prefill(q, k_pool, v_pool, table, case["start_pos"], 16, case["n_kv_heads"])
+    assert np.array_equal(paged.view(np.uint32), gold.view(np.uint32))  # paged == contiguous, per query
 
 
 @pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])

@@ -72,3 +72,19 @@ def test_apply_rope_bit_exact():
                 b = ol.apply_rope(ol.REF.ref_apply_rope, q, k, pos, hd, H, KV, theta)
                 assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
                 assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def test_chunked_prefill_attention_bit_exact():
+    """oracle_chunked_attention vs the reference's LlamaModelChunked::chunked_attention, and both vs the
+    decode attention applied per query (the identity the paged prefill kernels are checked through)."""
+    for seed, (H, KV, hd, start, C_) in enumerate([(6, 6, 48, 0, 20), (8, 2, 64, 13, 9), (32, 8, 128, 50, 17), (4, 4, 20, 3, 5)]):
+        T = start + C_
+        q = uniform(500 + seed, 0, C_ * H * hd).reshape(C_, H, hd)
+        k = uniform(510 + seed, 0, T * KV * hd).reshape(T, KV, hd)
+        v = uniform(520 + seed, 0, T * KV * hd).reshape(T, KV, hd)
+        a = ol.oracle_chunked_attention(q, k, v, start, KV)
+        b = ol.ref_chunked_attention(q, k, v, start, KV)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for bq in (0, C_ - 1):
+            one = ol.standard_attention(ol.REF.ref_standard_attention, q[bq], k, v, start + bq, hd, H, KV, T)
+            assert np.array_equal(one.view(np.uint32), b[bq].view(np.uint32))
