@@ -37,6 +37,11 @@ extern "C" {
 #define NVK_DECODE_SINGLE_PASS 1 /* one chunk per sequence, no workspace, no merge   */
 #define NVK_DECODE_SPLIT_K 2     /* flash-decoding: chunk_tokens per workgroup+merge */
 
+/* prefill flags */
+#define NVK_PREFILL_AUTO 0    /* library picks by chunk length                                      */
+#define NVK_PREFILL_ROWWISE 1 /* every query token is a decode row of its own: HBM-bound, short chunks */
+#define NVK_PREFILL_TILED 2   /* 32-query x 32-key fp32 MFMA tiles: K/V read once per tile, long chunks */
+
 /* pointer kinds for the *_ex entry points */
 #define NVK_PTR_HOST 0
 #define NVK_PTR_DEVICE 1
@@ -101,6 +106,17 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
                                const float *v_rows, const int *block_tables, int max_blocks, const int *positions,
                                float rope_theta, int ptr_kind, void *stream);
 
+/* The same for CHUNKS of new tokens: sequence s brings chunk_lens[s] tokens at
+ * positions chunk_starts[s] + b; rows of q / k_rows / v_rows are packed back to back in sequence order
+ * (sum of chunk_lens rows in all).  chunk_starts / chunk_lens are always HOST arrays; ptr_kind says
+ * where q, k_rows, v_rows and block_tables live.
+ * ref: BatchOps::batch_rope, experimental/chunked_prefill/batch_ops.hpp:25-56, and the append loop of
+ *      LlamaModelChunked::forward_chunk, experimental/chunked_prefill/model_chunked.hpp:79-94 (contiguous
+ *      cache there; through the block table here, as include/core/model.hpp:190-207 does per token). */
+int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_heads, float *q, const float *k_rows,
+                                const float *v_rows, const int *block_tables, int max_blocks, const int *chunk_starts,
+                                const int *chunk_lens, float rope_theta, int ptr_kind, void *stream);
+
 /* Whole-block transfers, host pointers, [block_size, n_kv_heads, head_dim] floats each. */
 int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const float *k_block,
                           const float *v_block);
@@ -141,6 +157,23 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
 int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
                       const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
                       float *out_dev, int flags, int chunk_tokens, void *stream);
+
+/* Paged chunked-prefill attention: causal attention of each sequence's chunk of
+ * new tokens over the paged pool.  Row (s, b) of out equals Attention::paged_attention
+ * (include/core/attention.hpp:82-159) with num_tokens = chunk_starts[s] + b + 1 over table row s --
+ * ref: LlamaModelChunked::chunked_attention, experimental/chunked_prefill/model_chunked.hpp:167-224
+ * (query b attends to t <= start_pos + b, :186), which only knows the contiguous cache.
+ * The chunk's own K/V rows must already be in the pool (nvk_pool_rope_append_chunks).
+ *   q, out  [sum(chunk_lens), n_heads, head_dim], packed in sequence order
+ *   chunk_starts, chunk_lens  HOST arrays [num_seqs] (the scheduler knows them: Request::current_pos,
+ *                             include/scheduler/request.hpp:70)
+ * nvk_prefill: host pointers, validates the tables, synchronises.  nvk_prefill_device: q / tables / out
+ * are device pointers, asynchronous on `stream` (NULL = the pool's stream). */
+int nvk_prefill(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q, const int *block_tables,
+                int max_blocks, const int *chunk_starts, const int *chunk_lens, float *out, int flags);
+int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                       const int *block_tables_dev, int max_blocks, const int *chunk_starts, const int *chunk_lens,
+                       float *out_dev, int flags, void *stream);
 
 /* Pre-size the split-K workspace and the pool's own plan so later
  * nvk_decode_device calls of up to this shape do not allocate. */

@@ -12,8 +12,9 @@ from .attention import AUTO, SINGLE_PASS, SPLIT_K, DecodePlan, bind_pool, decode
 from .batch import DecodeBatch
 from .block_manager import BlockManager
 from .kv_pool import PagedKVPool
+from .prefill import PREFILL_AUTO, PREFILL_ROWWISE, PREFILL_TILED, prefill, prefill_device, rope_append_chunks
 
 __all__ = [
-    "AUTO", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "NvkError", "PagedKVPool", "bind_pool", "decode",
-    "decode_bench", "decode_device", "device_count", "paged_attention", "standard_attention", "version",
+    "AUTO", "PREFILL_AUTO", "PREFILL_ROWWISE", "PREFILL_TILED", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "NvkError", "PagedKVPool", "bind_pool", "decode",
+    "decode_bench", "decode_device", "device_count", "paged_attention", "prefill", "prefill_device", "rope_append_chunks", "standard_attention", "version",
 ]

@@ -24,6 +24,10 @@ DECODE_AUTO = 0
 DECODE_SINGLE_PASS = 1
 DECODE_SPLIT_K = 2
 
+PREFILL_AUTO = 0
+PREFILL_ROWWISE = 1
+PREFILL_TILED = 2
+
 PTR_HOST = 0
 PTR_DEVICE = 1
 
@@ -64,6 +68,10 @@ SIGNATURES = {
     "nvk_pool_append_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "nvk_pool_rope_append_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp,
                                              C.c_float, C.c_int, _vp]),
+    "nvk_pool_rope_append_chunks": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp,
+                                              C.c_float, C.c_int, _vp]),
+    "nvk_prefill": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int]),
+    "nvk_prefill_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "nvk_pool_upload_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "nvk_pool_download_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "nvk_pool_gather": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),

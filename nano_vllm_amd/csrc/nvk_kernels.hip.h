@@ -74,6 +74,8 @@ struct DecodeParams
     const float    *v_layer;
     const float    *q;            // [num_seqs, n_heads, head_dim]
     const int      *block_tables; // [num_seqs, max_blocks]
+    const int      *table_rows;   // null, or [num_seqs]: row s of q/out reads table row table_rows[s]
+                                  // (chunked prefill: the query tokens of one sequence share its table)
     const WorkItem *items;        // [*n_items], written by nvk_plan_kernel
     const int      *n_items;
     float          *out;   // [num_seqs, n_heads, head_dim]
@@ -320,8 +322,9 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
 
     const int blk0 = token_block(t0, p.bs_magic);
     const int blk1 = token_block(t1 - 1, p.bs_magic);
+    const int trow = p.table_rows ? p.table_rows[seq] : seq;
     for (int i = threadIdx.x; i <= blk1 - blk0; i += blockDim.x)
-        s_tab[i] = clamp_block(p.block_tables[(int64_t)seq * p.max_blocks + blk0 + i], p.num_blocks);
+        s_tab[i] = clamp_block(p.block_tables[(int64_t)trow * p.max_blocks + blk0 + i], p.num_blocks);
     __syncthreads();
     if (!live)
         return; // no barrier after this point
@@ -617,9 +620,9 @@ __device__ __forceinline__ float2 rope_rotate(float2 v, float2 cs)
 __global__ void __launch_bounds__(256)
     nvk_rope_append_kernel(float *__restrict__ k_layer, float *__restrict__ v_layer, float *__restrict__ q,
                            const float *__restrict__ k_rows, const float *__restrict__ v_rows,
-                           const int *__restrict__ block_tables, int max_blocks, const int *__restrict__ positions,
-                           const float *__restrict__ inv_freq, int num_blocks, int block_size, unsigned bs_magic,
-                           int n_heads, int n_kv_heads, int head_dim)
+                           const int *__restrict__ block_tables, const int *__restrict__ table_rows, int max_blocks,
+                           const int *__restrict__ positions, const float *__restrict__ inv_freq, int num_blocks,
+                           int block_size, unsigned bs_magic, int n_heads, int n_kv_heads, int head_dim)
 {
     extern __shared__ __attribute__((aligned(16))) float2 s_cs[]; // [head_dim / 2] (cos, sin)
     const int seq = blockIdx.x;
@@ -651,7 +654,8 @@ __global__ void __launch_bounds__(256)
     const int     row_len = n_kv_heads * head_dim;
     const int     blk     = token_block(pos, bs_magic);
     const int     off     = token_offset(pos, blk, block_size);
-    const int     pb      = clamp_block(block_tables[(int64_t)seq * max_blocks + blk], num_blocks);
+    const int     trow    = table_rows ? table_rows[seq] : seq; // chunked prefill: several rows per table row
+    const int     pb      = clamp_block(block_tables[(int64_t)trow * max_blocks + blk], num_blocks);
     const int64_t at      = ((int64_t)pb * block_size + off) * row_len;
     const float2 *k2      = reinterpret_cast<const float2 *>(k_rows + (int64_t)seq * row_len);
     float2       *kd      = reinterpret_cast<float2 *>(k_layer + at);

@@ -105,6 +105,11 @@ struct nvk_pool
 
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
 
+    // chunk descriptors of the prefill entry points: pinned host staging and its device mirror
+    int       *desc_host = nullptr, *desc_dev = nullptr;
+    size_t     desc_cap  = 0;       // ints
+    hipEvent_t desc_ev   = nullptr; // the last copy out of desc_host has finished
+
     // RoPE inverse frequencies for (rope_theta, head_dim), computed on the host with libm
     float *rope_inv_freq = nullptr; // [head_dim / 2] on the device
     float  rope_theta    = 0.f;     // 0 = table not built
@@ -352,7 +357,7 @@ int build_plan(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, in
 // ev_attn_begin/ev_attn_end (optional) bracket the attention kernel alone.
 int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float *q_dev, const int *tables_dev,
                     int max_blocks, float *out_dev, hipStream_t stream, hipEvent_t ev_attn_begin,
-                    hipEvent_t ev_attn_end)
+                    hipEvent_t ev_attn_end, const int *table_rows_dev = nullptr)
 {
     if (!plan->built || plan->pool != pool)
         return nvk::fail(NVK_ERR_INVALID_ARG, "decode: the plan was not built for this pool");
@@ -374,6 +379,7 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     p.v_layer      = pool->v_layer(layer);
     p.q            = q_dev;
     p.block_tables = tables_dev;
+    p.table_rows   = table_rows_dev;
     p.items        = plan->items;
     p.n_items      = plan->counters;
     p.out          = out_dev;
@@ -446,6 +452,94 @@ int enqueue_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const f
     if (rc != NVK_OK)
         return rc;
     return enqueue_planned(pool, layer, plan, q_dev, tables_dev, max_blocks, out_dev, stream, nullptr, nullptr);
+}
+
+// ---- chunked prefill: descriptors -------------------------------------------
+// Sequence s brings lens[s] new tokens at positions starts[s] + b; their q/k/v/out rows are packed back
+// to back in sequence order.  Row r of the packed arrays is described by (row_seq, row_pos, row_ctx).
+struct ChunkRows
+{
+    int        total_q = 0, max_ctx = 0, max_chunk = 0;
+    const int *row_seq = nullptr, *row_pos = nullptr, *row_ctx = nullptr; // device pointers, [total_q] each
+};
+
+int ensure_desc(nvk_pool *pool, size_t ints)
+{
+    if (!pool->desc_ev)
+        HIP_TRY(hipEventCreateWithFlags(&pool->desc_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventSynchronize(pool->desc_ev)); // the pinned buffer is ours again
+    if (ints <= pool->desc_cap)
+        return NVK_OK;
+    if (pool->desc_host) {
+        HIP_TRY(hipDeviceSynchronize()); // kernels may still read the old device mirror
+        HIP_TRY(hipHostFree(pool->desc_host));
+        HIP_TRY(hipFree(pool->desc_dev));
+        pool->desc_host = pool->desc_dev = nullptr;
+        pool->desc_cap                   = 0;
+    }
+    const size_t want = std::max(ints, (size_t)16384);
+    HIP_TRY(hipHostMalloc((void **)&pool->desc_host, want * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&pool->desc_dev, want * sizeof(int)));
+    pool->desc_cap = want;
+    return NVK_OK;
+}
+
+// Validates the chunk list (host arrays), builds the per-row descriptors and uploads them on `st`.
+int stage_chunk_rows(nvk_pool *pool, int num_seqs, const int *starts, const int *lens, int max_blocks, const char *who,
+                     hipStream_t st, ChunkRows *rows)
+{
+    long long total = 0;
+    int       max_ctx = 0, max_chunk = 0;
+    for (int s = 0; s < num_seqs; s++) {
+        if (starts[s] < 0 || lens[s] < 0)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "%s: chunk %d has start %d, length %d", who, s, starts[s], lens[s]);
+        const long long end = (long long)starts[s] + lens[s];
+        if (end > (long long)max_blocks * pool->block_size)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "%s: chunk %d ends at token %lld, its table row holds %d blocks of %d",
+                             who, s, end, max_blocks, pool->block_size);
+        total += lens[s];
+        if (lens[s] > 0)
+            max_ctx = std::max(max_ctx, (int)end);
+        max_chunk = std::max(max_chunk, lens[s]);
+    }
+    if (total > 0x3fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld query tokens in one call", who, total);
+    rows->total_q = (int)total, rows->max_ctx = max_ctx, rows->max_chunk = max_chunk;
+    if (total == 0)
+        return NVK_OK;
+    int rc = ensure_desc(pool, (size_t)3 * total);
+    if (rc != NVK_OK)
+        return rc;
+    int *seq = pool->desc_host, *pos = seq + total, *ctx = pos + total;
+    int  r = 0;
+    for (int s = 0; s < num_seqs; s++)
+        for (int b = 0; b < lens[s]; b++, r++) {
+            seq[r] = s;
+            pos[r] = starts[s] + b;
+            ctx[r] = starts[s] + b + 1; // query b attends to t <= start + b (model_chunked.hpp:186)
+        }
+    HIP_TRY(hipMemcpyAsync(pool->desc_dev, pool->desc_host, (size_t)3 * total * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(pool->desc_ev, st));
+    rows->row_seq = pool->desc_dev, rows->row_pos = pool->desc_dev + total, rows->row_ctx = pool->desc_dev + 2 * total;
+    return NVK_OK;
+}
+
+// Host-side check of every table entry the chunks reach (what the reference leaves undefined).
+int validate_chunk_tables(const nvk_pool *pool, int num_seqs, const int *tables, int max_blocks, const int *starts,
+                          const int *lens, const char *who)
+{
+    for (int s = 0; s < num_seqs; s++) {
+        if (lens[s] <= 0)
+            continue;
+        const int nblk = (starts[s] + lens[s] + pool->block_size - 1) / pool->block_size;
+        for (int i = 0; i < nblk; i++) {
+            const int pb = tables[(size_t)s * max_blocks + i];
+            if (pb < 0 || pb >= pool->num_blocks)
+                return nvk::fail(NVK_ERR_BAD_BLOCK, "%s: block_tables[%d][%d]=%d outside [0,%d)", who, s, i, pb,
+                                 pool->num_blocks);
+        }
+    }
+    return NVK_OK;
 }
 
 // thread-local binding for the drop-in entry point
@@ -574,6 +668,12 @@ int nvk_pool_destroy(nvk_pool *pool)
     free_plan(pool->own_plan);
     if (pool->rope_inv_freq)
         (void)hipFree(pool->rope_inv_freq);
+    if (pool->desc_host)
+        (void)hipHostFree(pool->desc_host);
+    if (pool->desc_dev)
+        (void)hipFree(pool->desc_dev);
+    if (pool->desc_ev)
+        (void)hipEventDestroy(pool->desc_ev);
     if (pool->stage)
         (void)hipFree(pool->stage);
     if (pool->ev_a)
@@ -777,7 +877,7 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: ptr_kind %d", ptr_kind);
     }
     hipLaunchKernelGGL(nvk::nvk_rope_append_kernel, dim3((unsigned)num_seqs), dim3(256), (size_t)half * sizeof(float2), st,
-                       pool->k_layer(layer), pool->v_layer(layer), dq, dk, dv, dt, max_blocks, dp,
+                       pool->k_layer(layer), pool->v_layer(layer), dq, dk, dv, dt, (const int *)nullptr, max_blocks, dp,
                        rotate ? pool->rope_inv_freq : (const float *)nullptr,
                        pool->num_blocks, pool->block_size, pool->bs_magic, n_heads, pool->n_kv_heads, hd);
     HIP_TRY(hipGetLastError());
@@ -1116,6 +1216,158 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
         *total_ms = whole / iters;
     if (attn_ms)
         *attn_ms = (float)(kernels / n_samples);
+    return NVK_OK;
+}
+
+int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_heads, float *q, const float *k_rows,
+                                const float *v_rows, const int *block_tables, int max_blocks, const int *chunk_starts,
+                                const int *chunk_lens, float rope_theta, int ptr_kind, void *stream)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_pool_rope_append_chunks");
+    if (rc != NVK_OK)
+        return rc;
+    const bool rotate = rope_theta > 0.f;
+    if (num_seqs < 0 || max_blocks <= 0 || n_heads <= 0 || !(rope_theta >= 0.f)
+        || (num_seqs > 0 && (!chunk_starts || !chunk_lens || !block_tables || !k_rows || !v_rows || (rotate && !q))))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_chunks: bad arguments");
+    if (ptr_kind != NVK_PTR_HOST && ptr_kind != NVK_PTR_DEVICE)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_chunks: ptr_kind %d", ptr_kind);
+    if (num_seqs == 0)
+        return NVK_OK;
+    DeviceScope scope(pool->device);
+    hipStream_t st = (ptr_kind == NVK_PTR_DEVICE && stream) ? (hipStream_t)stream : pool->stream;
+    if (ptr_kind == NVK_PTR_HOST) {
+        rc = validate_chunk_tables(pool, num_seqs, block_tables, max_blocks, chunk_starts, chunk_lens,
+                                   "nvk_pool_rope_append_chunks");
+        if (rc != NVK_OK)
+            return rc;
+    }
+    ChunkRows rows;
+    rc = stage_chunk_rows(pool, num_seqs, chunk_starts, chunk_lens, max_blocks, "nvk_pool_rope_append_chunks", st, &rows);
+    if (rc != NVK_OK || rows.total_q == 0)
+        return rc;
+    const int hd = pool->head_dim, half = hd / 2, row = pool->row_len();
+    if (rotate && (!pool->rope_inv_freq || pool->rope_theta != rope_theta)) {
+        std::vector<float> freq((size_t)half);
+        for (int i = 0; i < hd; i += 2)
+            freq[(size_t)(i / 2)] = 1.0f / powf(rope_theta, (float)i / hd); // positional.hpp:16 / batch_ops.hpp:34
+        if (!pool->rope_inv_freq)
+            HIP_TRY(hipMalloc(&pool->rope_inv_freq, (size_t)half * sizeof(float)));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(pool->rope_inv_freq, freq.data(), (size_t)half * sizeof(float), hipMemcpyHostToDevice));
+        pool->rope_theta = rope_theta;
+    }
+    float       *dq = q;
+    const float *dk = k_rows, *dv = v_rows;
+    const int   *dt = block_tables;
+    const size_t q_b = (size_t)rows.total_q * n_heads * hd * sizeof(float);
+    if (ptr_kind == NVK_PTR_HOST) {
+        const size_t rows_b = (size_t)rows.total_q * row * sizeof(float);
+        const size_t tab_b  = (size_t)num_seqs * max_blocks * sizeof(int);
+        auto         al     = [](size_t b) { return (b + 255) / 256 * 256; };
+        rc = ensure_stage(pool, al(q_b) + 2 * al(rows_b) + al(tab_b));
+        if (rc != NVK_OK)
+            return rc;
+        char *base = pool->stage;
+        dq         = (float *)base;
+        dk         = (const float *)(base + al(q_b));
+        dv         = (const float *)(base + al(q_b) + al(rows_b));
+        dt         = (const int *)(base + al(q_b) + 2 * al(rows_b));
+        if (rotate)
+            HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)dk, k_rows, rows_b, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)dv, v_rows, rows_b, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)dt, block_tables, tab_b, hipMemcpyHostToDevice, st));
+    }
+    // one workgroup per new token: batch_rope (batch_ops.hpp:25-56) and the append loop (model_chunked.hpp:82-94)
+    hipLaunchKernelGGL(nvk::nvk_rope_append_kernel, dim3((unsigned)rows.total_q), dim3(256), (size_t)half * sizeof(float2),
+                       st, pool->k_layer(layer), pool->v_layer(layer), dq, dk, dv, dt, rows.row_seq, max_blocks,
+                       rows.row_pos, rotate ? pool->rope_inv_freq : (const float *)nullptr, pool->num_blocks,
+                       pool->block_size, pool->bs_magic, n_heads, pool->n_kv_heads, hd);
+    HIP_TRY(hipGetLastError());
+    if (ptr_kind == NVK_PTR_HOST) {
+        if (rotate)
+            HIP_TRY(hipMemcpyAsync(q, dq, q_b, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return NVK_OK;
+}
+
+int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                       const int *block_tables_dev, int max_blocks, const int *chunk_starts, const int *chunk_lens,
+                       float *out_dev, int flags, void *stream)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_prefill_device");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_seqs < 0 || max_blocks <= 0 || n_heads <= 0
+        || (num_seqs > 0 && (!chunk_starts || !chunk_lens || !block_tables_dev || !q_dev || !out_dev)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_prefill_device: bad arguments");
+    if (flags != NVK_PREFILL_AUTO && flags != NVK_PREFILL_ROWWISE && flags != NVK_PREFILL_TILED)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_prefill_device: flags %d", flags);
+    if (num_seqs == 0)
+        return NVK_OK;
+    DeviceScope scope(pool->device);
+    hipStream_t st = stream ? (hipStream_t)stream : pool->stream;
+    ChunkRows   rows;
+    rc = stage_chunk_rows(pool, num_seqs, chunk_starts, chunk_lens, max_blocks, "nvk_prefill_device", st, &rows);
+    if (rc != NVK_OK || rows.total_q == 0)
+        return rc;
+    // ROWWISE: every query token is a decode row of its own (ctx = pos + 1) that reads its sequence's table
+    // row; K/V are streamed once per query token, so this is the HBM-bound form, right for short chunks.
+    nvk_plan *plan = nullptr;
+    rc             = own_plan_of(pool, &plan);
+    if (rc != NVK_OK)
+        return rc;
+    rc = build_plan(plan, rows.total_q, n_heads, rows.row_ctx, rows.max_ctx, NVK_DECODE_AUTO, 0, st);
+    if (rc != NVK_OK)
+        return rc;
+    return enqueue_planned(pool, layer, plan, q_dev, block_tables_dev, max_blocks, out_dev, st, nullptr, nullptr,
+                           rows.row_seq);
+}
+
+int nvk_prefill(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q, const int *block_tables,
+                int max_blocks, const int *chunk_starts, const int *chunk_lens, float *out, int flags)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_prefill");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_seqs < 0 || max_blocks <= 0 || n_heads <= 0
+        || (num_seqs > 0 && (!chunk_starts || !chunk_lens || !block_tables || !q || !out)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_prefill: bad arguments");
+    if (num_seqs == 0)
+        return NVK_OK;
+    long long total = 0;
+    for (int s = 0; s < num_seqs; s++) {
+        if (chunk_starts[s] < 0 || chunk_lens[s] < 0
+            || (long long)chunk_starts[s] + chunk_lens[s] > (long long)max_blocks * pool->block_size)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_prefill: chunk %d (start %d, length %d) does not fit its table row",
+                             s, chunk_starts[s], chunk_lens[s]);
+        total += chunk_lens[s];
+    }
+    rc = validate_chunk_tables(pool, num_seqs, block_tables, max_blocks, chunk_starts, chunk_lens, "nvk_prefill");
+    if (rc != NVK_OK)
+        return rc;
+    if (total == 0)
+        return NVK_OK;
+    DeviceScope  scope(pool->device);
+    const size_t q_b   = (size_t)total * n_heads * pool->head_dim * sizeof(float);
+    const size_t tab_b = (size_t)num_seqs * max_blocks * sizeof(int);
+    auto         al    = [](size_t b) { return (b + 255) / 256 * 256; };
+    rc                 = ensure_stage(pool, 2 * al(q_b) + al(tab_b));
+    if (rc != NVK_OK)
+        return rc;
+    float *dq   = (float *)pool->stage;
+    float *dout = (float *)(pool->stage + al(q_b));
+    int   *dtab = (int *)(pool->stage + 2 * al(q_b));
+    HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, pool->stream));
+    HIP_TRY(hipMemcpyAsync(dtab, block_tables, tab_b, hipMemcpyHostToDevice, pool->stream));
+    rc = nvk_prefill_device(pool, layer, num_seqs, n_heads, dq, dtab, max_blocks, chunk_starts, chunk_lens, dout, flags,
+                            (void *)pool->stream);
+    if (rc != NVK_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, q_b, hipMemcpyDeviceToHost, pool->stream));
+    HIP_TRY(hipStreamSynchronize(pool->stream));
     return NVK_OK;
 }
 
