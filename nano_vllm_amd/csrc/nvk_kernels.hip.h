@@ -599,6 +599,214 @@ __global__ void nvk_append_kernel(float *__restrict__ k_layer, float *__restrict
     }
 }
 
+// ---- paged chunked prefill on fp32 MFMA tiles -----------
+// Reference maths: LlamaModelChunked::chunked_attention (experimental/chunked_prefill/
+// model_chunked.hpp:167-224): query b of a chunk attends to keys t <= start_pos + b.  Here K/V
+// come through the block table (attention.hpp:109-115) and every K/V tile is read from HBM once
+// per 32..128 queries x all grouped q-heads instead of once per (query, head).
+//
+//   * work item = (sequence, tile of up to 32*qsubs consecutive query tokens); blockIdx.y =
+//     (kv-head, q-head sub-group).  4 waves: wave w owns q-head (w % hpw) of the group and query
+//     sub-tile (w / hpw) of 32 tokens; all four share each 32-key K/V tile through LDS.
+//   * S^T[key][query] = K . Q^T on v_mfma_f32_32x32x2_f32 (exact fp32, an fmaf chain): A = K tile
+//     rows from LDS, B = the wave's Q fragment held in registers for the whole key loop.  The k
+//     index of the instruction is re-associated: lane half h covers dims [h*HDP/2, (h+1)*HDP/2),
+//     so a lane's operands are contiguous floats (ds_read_b128, float4 global loads).
+//   * the result has the query on the lane and the 32 keys in 16 registers x 2 lane halves
+//     (row = (r&3) + 8*(r>>2) + 4*half), so the online-softmax statistics are per lane plus one
+//     exchange with lane^32, and register r is directly the B operand of the second product
+//     O^T[dim][query] += V^T[dim][key] . P^T[key][query] (A = V from LDS, one float per lane):
+//     no transpose, no LDS round trip for P.
+//   * softmax in the exp2 domain, running max seeded finite, the reference's -1e10 floor applied
+//     at the end (as in nvk_decode_kernel).  Keys past a query's position are masked to -inf
+//     only in the tiles that straddle the diagonal.
+//   * next K/V tile is fetched global -> registers while the current one is consumed.
+// Bound: fp32 MFMA (64 FLOP/clk/SIMD); 128 MFMAs of 64 cycles per wave per 32x32 tile at HDP = 128.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct __attribute__((aligned(16))) PrefillItem
+{
+    int seq, row0, pos0, nq; // table row, first packed q/out row, position of that query, queries in the tile
+};
+
+struct PrefillParams
+{
+    const float       *k_layer, *v_layer, *q;
+    const int         *block_tables;
+    const PrefillItem *items;
+    float             *out;
+    int                max_blocks, num_blocks, block_size;
+    unsigned           bs_magic;
+    int                n_kv_heads, n_heads, kv_mul, head_dim;
+    int                hpw; // q-heads of one kv-head per workgroup: 1, 2 or 4 (divides kv_mul)
+    float              q_scale;
+};
+
+template <int HDP> __global__ void __launch_bounds__(256) nvk_prefill_kernel(const PrefillParams p)
+{
+    constexpr int KS  = HDP + 4; // K tile row stride in floats: 16 lanes x b128 land in 64 different banks
+    constexpr int VS  = HDP + 8; // V tile row stride: rows r and r+4 (the two lane halves) 32 banks apart
+    constexpr int VPT = HDP / 32; // float4 per thread per tile (32 rows x HDP/4 vectors over 256 threads)
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float *s_k   = s_mem;
+    float *s_v   = s_mem + 32 * KS;
+    int   *s_tab = reinterpret_cast<int *>(s_v + 32 * VS);
+
+    const PrefillItem item = p.items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int hpw    = p.hpw;
+    const int groups = p.kv_mul / hpw;
+    const int kvh    = blockIdx.y / groups;
+    const int head   = kvh * p.kv_mul + (blockIdx.y % groups) * hpw + wave % hpw;
+    const int wq0    = 32 * (wave / hpw);            // first query of this wave inside the item
+    const int my_nq  = min(32, item.nq - wq0);       // <= 0: the wave only helps with the loads
+    const bool q_live = j < my_nq;
+    const int qpos   = q_live ? item.pos0 + wq0 + j : 0x7fffffff; // dead lanes mask nothing, store nothing
+    const int hd     = p.head_dim;
+    const int kmax   = item.pos0 + item.nq - 1;      // last key any query of the item sees
+    const int row_len = p.n_kv_heads * hd;
+
+    const int nblk = token_block(kmax, p.bs_magic) + 1;
+    for (int i = tid; i < nblk; i += 256)
+        s_tab[i] = clamp_block(p.block_tables[(int64_t)item.seq * p.max_blocks + i], p.num_blocks);
+
+    // this wave's Q fragment: lane (query j, half) holds dims [half*HDP/2, (half+1)*HDP/2), pre-scaled
+    float qf[HDP / 2];
+    {
+        const float *qrow = p.q + ((int64_t)(item.row0 + wq0 + j) * p.n_heads + head) * hd;
+#pragma unroll
+        for (int s4 = 0; s4 < HDP / 8; s4++) {
+            const int d = half * (HDP / 2) + 4 * s4;
+            float4    v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q_live && d < hd)
+                v = *reinterpret_cast<const float4 *>(qrow + d);
+            qf[4 * s4 + 0] = v.x * p.q_scale, qf[4 * s4 + 1] = v.y * p.q_scale;
+            qf[4 * s4 + 2] = v.z * p.q_scale, qf[4 * s4 + 3] = v.w * p.q_scale;
+        }
+    }
+    __syncthreads(); // table slice staged
+
+    float4 kreg[VPT], vreg[VPT];
+    auto fetch_tile = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const int idx = tid + 256 * u;
+            const int row = idx / (HDP / 4), c4 = idx % (HDP / 4);
+            const int tok = t0 + row;
+            kreg[u] = vreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tok <= kmax && 4 * c4 < hd) {
+                const int     blk = token_block(tok, p.bs_magic);
+                const int     off = token_offset(tok, blk, p.block_size);
+                const int64_t at  = ((int64_t)s_tab[blk] * p.block_size + off) * row_len + kvh * hd + 4 * c4;
+                kreg[u]           = *reinterpret_cast<const float4 *>(p.k_layer + at);
+                vreg[u]           = *reinterpret_cast<const float4 *>(p.v_layer + at);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const int idx = tid + 256 * u;
+            const int row = idx / (HDP / 4), c4 = idx % (HDP / 4);
+            *reinterpret_cast<float4 *>(s_k + row * KS + 4 * c4) = kreg[u];
+            *reinterpret_cast<float4 *>(s_v + row * VS + 4 * c4) = vreg[u];
+        }
+    };
+
+    float  m = kNegBig, l = 0.f;
+    f32x16 o[HDP / 32];
+#pragma unroll
+    for (int c = 0; c < HDP / 32; c++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            o[c][r] = 0.f;
+
+    const int ntiles    = kmax / 32 + 1;
+    const int wave_last = item.pos0 + wq0 + my_nq - 1; // last position this wave's queries reach
+    fetch_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int it = 0; it < ntiles; it++) {
+        const int t0 = 32 * it;
+        if (it + 1 < ntiles)
+            fetch_tile(t0 + 32);
+        if (my_nq > 0 && t0 <= wave_last) { // wave-uniform
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                sacc[r] = 0.f;
+            const float *krow = s_k + j * KS + half * (HDP / 2); // A operand: key row = lane & 31
+#pragma unroll
+            for (int s4 = 0; s4 < HDP / 8; s4++) {
+                const float4 kv = *reinterpret_cast<const float4 *>(krow + 4 * s4);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qf[4 * s4 + 0], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf[4 * s4 + 1], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qf[4 * s4 + 2], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf[4 * s4 + 3], sacc, 0, 0, 0);
+            }
+            // keys after the query's own position are not attended to (model_chunked.hpp:186)
+            if (t0 + 31 > item.pos0 + wq0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = t0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (key > qpos || key > kmax)
+                        sacc[r] = -INFINITY;
+                }
+            }
+            float mx = sacc[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++)
+                mx = fmaxf(mx, sacc[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn    = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - mn);
+            float       psum  = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sacc[r] = fast_exp2(sacc[r] - mn);
+                psum += sacc[r];
+            }
+            m = mn;
+            l = fmaf(l, alpha, psum); // this lane half's share of the row sum; joined at the end
+#pragma unroll
+            for (int c = 0; c < HDP / 32; c++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    o[c][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int   key = (r & 3) + 8 * (r >> 2) + 4 * half; // the key register r of this half holds
+                    const float vv  = s_v[key * VS + 32 * c + j];        // A operand: dim = 32c + (lane & 31)
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sacc[r], o[c], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads(); // every wave is done with this tile
+        if (it + 1 < ntiles) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    if (!q_live)
+        return;
+    l += __shfl_xor(l, 32); // q_live is the same for lane and lane^32
+    const float mf  = fmaxf(m, kRefMaxFloorLog2); // the reference's max_val = -1e10 floor (model_chunked.hpp:197)
+    const float f   = fast_exp2(m - mf);
+    const float inv = f / (l * f);
+    float      *orow = p.out + ((int64_t)(item.row0 + wq0 + j) * p.n_heads + head) * hd;
+#pragma unroll
+    for (int c = 0; c < HDP / 32; c++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int dim = 32 * c + 8 * g + 4 * half; // registers 4g..4g+3 are four consecutive dims
+            if (dim < hd)
+                *reinterpret_cast<float4 *>(orow + dim) = make_float4(o[c][4 * g] * inv, o[c][4 * g + 1] * inv,
+                                                                      o[c][4 * g + 2] * inv, o[c][4 * g + 3] * inv);
+        }
+}
+
 // ---- RoPE fused with the batched KV append --------------
 // Reference: Ops::apply_rope (ops/positional.hpp:13-39) as called at model.hpp:169-175,
 // then the append at model.hpp:190-207.  grid.x = sequences.  Per sequence:

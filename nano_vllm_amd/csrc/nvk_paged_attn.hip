@@ -524,6 +524,44 @@ int stage_chunk_rows(nvk_pool *pool, int num_seqs, const int *starts, const int 
     return NVK_OK;
 }
 
+constexpr int kPrefillMaxTableEntries = 4096; // table slice a tiled-prefill workgroup stages in LDS (16 KiB)
+
+// TILED prefill: one work item per (sequence, tile of 32*qsubs query tokens), longest key range first.
+// Built on the host from the chunk list and uploaded on `st`.  *n_items = 0 when nothing is to be done.
+int stage_prefill_items(nvk_pool *pool, int num_seqs, const int *starts, const int *lens, int max_blocks, int qsubs,
+                        hipStream_t st, const nvk::PrefillItem **items_dev, int *n_items, int *max_ctx)
+{
+    std::vector<nvk::PrefillItem> items;
+    const int                     tile = 32 * qsubs;
+    int                           row = 0, top = 0;
+    for (int s = 0; s < num_seqs; s++) {
+        if (starts[s] < 0 || lens[s] < 0 || (long long)starts[s] + lens[s] > (long long)max_blocks * pool->block_size)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "prefill: chunk %d (start %d, length %d) does not fit its table row", s,
+                             starts[s], lens[s]);
+        for (int q0 = 0; q0 < lens[s]; q0 += tile)
+            items.push_back(nvk::PrefillItem{s, row + q0, starts[s] + q0, std::min(tile, lens[s] - q0)});
+        row += lens[s];
+        if (lens[s] > 0)
+            top = std::max(top, starts[s] + lens[s]);
+    }
+    *n_items = (int)items.size();
+    *max_ctx = top;
+    if (items.empty())
+        return NVK_OK;
+    std::stable_sort(items.begin(), items.end(), [](const nvk::PrefillItem &a, const nvk::PrefillItem &b) {
+        return a.pos0 + a.nq > b.pos0 + b.nq; // the longest key ranges start first
+    });
+    int rc = ensure_desc(pool, items.size() * 4);
+    if (rc != NVK_OK)
+        return rc;
+    std::memcpy(pool->desc_host, items.data(), items.size() * sizeof(nvk::PrefillItem));
+    HIP_TRY(hipMemcpyAsync(pool->desc_dev, pool->desc_host, items.size() * sizeof(nvk::PrefillItem),
+                           hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(pool->desc_ev, st));
+    *items_dev = reinterpret_cast<const nvk::PrefillItem *>(pool->desc_dev);
+    return NVK_OK;
+}
+
 // Host-side check of every table entry the chunks reach (what the reference leaves undefined).
 int validate_chunk_tables(const nvk_pool *pool, int num_seqs, const int *tables, int max_blocks, const int *starts,
                           const int *lens, const char *who)
@@ -1309,7 +1347,53 @@ int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, con
         return NVK_OK;
     DeviceScope scope(pool->device);
     hipStream_t st = stream ? (hipStream_t)stream : pool->stream;
-    ChunkRows   rows;
+    if (n_heads % pool->n_kv_heads != 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "n_heads=%d is not a positive multiple of n_kv_heads=%d", n_heads,
+                         pool->n_kv_heads);
+
+    // TILED (fp32 MFMA): K/V read once per tile of queries.  Needs head_dim <= 128 and contexts whose table
+    // slice fits a workgroup's LDS; AUTO takes it when some chunk is long enough to fill tiles.
+    int max_chunk = 0, top = 0;
+    for (int s = 0; s < num_seqs; s++) {
+        max_chunk = std::max(max_chunk, chunk_lens[s]);
+        if (chunk_lens[s] > 0)
+            top = std::max(top, chunk_starts[s] + chunk_lens[s]);
+    }
+    const bool tiled_ok = pool->head_dim <= 128 && pool->head_dim % 4 == 0
+                          && (top + pool->block_size - 1) / pool->block_size <= kPrefillMaxTableEntries;
+    if (flags == NVK_PREFILL_TILED && !tiled_ok)
+        return nvk::fail(NVK_ERR_INVALID_ARG,
+                         "nvk_prefill_device: NVK_PREFILL_TILED needs head_dim <= 128 and at most %d blocks per sequence",
+                         kPrefillMaxTableEntries);
+    if (flags == NVK_PREFILL_TILED || (flags == NVK_PREFILL_AUTO && tiled_ok && max_chunk >= 8)) {
+        const int kv_mul = n_heads / pool->n_kv_heads;
+        const int hpw    = kv_mul % 4 == 0 ? 4 : (kv_mul % 2 == 0 ? 2 : 1);
+        const nvk::PrefillItem *items = nullptr;
+        int                     n_items = 0, max_ctx = 0;
+        rc = stage_prefill_items(pool, num_seqs, chunk_starts, chunk_lens, max_blocks, 4 / hpw, st, &items, &n_items,
+                                 &max_ctx);
+        if (rc != NVK_OK || n_items == 0)
+            return rc;
+        nvk::PrefillParams pp;
+        pp.k_layer = pool->k_layer(layer), pp.v_layer = pool->v_layer(layer), pp.q = q_dev;
+        pp.block_tables = block_tables_dev, pp.items = items, pp.out = out_dev;
+        pp.max_blocks = max_blocks, pp.num_blocks = pool->num_blocks, pp.block_size = pool->block_size;
+        pp.bs_magic = pool->bs_magic, pp.n_kv_heads = pool->n_kv_heads, pp.n_heads = n_heads, pp.kv_mul = kv_mul;
+        pp.head_dim = pool->head_dim, pp.hpw = hpw;
+        pp.q_scale  = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
+        const int    hdp  = pool->head_dim <= 64 ? 64 : 128;
+        const int    nblk = (max_ctx + pool->block_size - 1) / pool->block_size;
+        const size_t lds  = ((size_t)32 * (hdp + 4) + (size_t)32 * (hdp + 8)) * sizeof(float) + (size_t)(nblk + 1) * sizeof(int);
+        const dim3   grid((unsigned)n_items, (unsigned)(pool->n_kv_heads * (kv_mul / hpw)));
+        if (hdp == 64)
+            hipLaunchKernelGGL((nvk::nvk_prefill_kernel<64>), grid, dim3(256), lds, st, pp);
+        else
+            hipLaunchKernelGGL((nvk::nvk_prefill_kernel<128>), grid, dim3(256), lds, st, pp);
+        HIP_TRY(hipGetLastError());
+        return NVK_OK;
+    }
+
+    ChunkRows rows;
     rc = stage_chunk_rows(pool, num_seqs, chunk_starts, chunk_lens, max_blocks, "nvk_prefill_device", st, &rows);
     if (rc != NVK_OK || rows.total_q == 0)
         return rc;
