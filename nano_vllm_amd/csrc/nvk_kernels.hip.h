@@ -322,7 +322,11 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
 
     const int blk0 = token_block(t0, p.bs_magic);
     const int blk1 = token_block(t1 - 1, p.bs_magic);
+#ifdef NVK_NO_TABLE_ROWS // A/B build: the decode kernel without the prefill indirection
+    const int trow = seq;
+#else
     const int trow = p.table_rows ? p.table_rows[seq] : seq;
+#endif
     for (int i = threadIdx.x; i <= blk1 - blk0; i += blockDim.x)
         s_tab[i] = clamp_block(p.block_tables[(int64_t)trow * p.max_blocks + blk0 + i], p.num_blocks);
     __syncthreads();
