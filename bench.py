@@ -37,9 +37,19 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def make_workload(name, rank=0):
+GEOMS = {"llama": (32, 8, 128, 16), "mha": (32, 32, 128, 16), "tiny": (6, 6, 48, 16), "shard2": (16, 4, 128, 16),
+         "shard8": (4, 1, 128, 16), "d64": (32, 8, 64, 16), "d256": (16, 4, 256, 16)}
+
+
+def make_workload(name, rank=0, geom="llama"):
     from nano_vllm_amd import workloads as wl
 
+    if geom != "llama":  # diagnostic sweeps over head geometry (shardN = one rank's share of a head-sharded G-llama)
+        g = wl.Geometry(*GEOMS[geom])
+        w = {"config2": lambda: wl.config2(g), "config3": lambda: wl.config3(256, g), "config4": lambda: wl.config4(g),
+             "5a": lambda: wl.config5a(512, g, first_seq=512 * rank), "5b": lambda: wl.config5b(512, g)}[name]()
+        w.name += f"_{geom}"
+        return w
     if name == "config2":
         return wl.config2()
     if name == "config3":
@@ -165,6 +175,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config2")
+    ap.add_argument("--geom", default="llama", choices=sorted(GEOMS), help="diagnostic: head geometry of the workload")
     ap.add_argument("--shard", default="seq", choices=["seq", "heads"],
                     help="seq: a private batch per GPU, no collective (default); heads: kv-head groups per GPU, "
                          "one RCCL all-gather of out per layer-call")
@@ -173,6 +184,9 @@ def main():
     ap.add_argument("--replan", type=int, default=1,
                     help="rebuild the decode plan every N layer-calls inside the timed region "
                          "(1 = every call; 32 = as for the 32 layers of one model step)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1: nccl (= RCCL, the real one) or gloo (rehearsal of the "
+                         "multi-process path on a box with fewer GPUs than ranks; ranks then share GPUs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no per-kernel event pairs inside the timed region (roofline from step time)")
@@ -188,13 +202,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if nv.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()  # rehearsal: more ranks than GPUs
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the timing reduction lives
 
-    work = make_workload(args.workload, rank)
+    work = make_workload(args.workload, rank, args.geom)
     g = work.geom
     flags = {"auto": nv.AUTO, "single": nv.SINGLE_PASS, "split": nv.SPLIT_K}[args.mode]
 
@@ -248,7 +268,10 @@ def main():
         def step():
             nv.decode_device(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
                              flags, args.chunk, stream=stream)
-            hs.all_gather_out(out, gathered)
+            if args.backend == "nccl":
+                hs.all_gather_out(out, gathered)
+            else:  # gloo rehearsal: the collective runs on host copies
+                gathered.copy_(hs.all_gather_out(out.cpu()))
 
         for _ in range(args.warmup):
             step()
@@ -268,7 +291,7 @@ def main():
         torch.cuda.synchronize()
 
     if world > 1:
-        t = torch.tensor([wall, step_ms, attn_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, step_ms, attn_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, step_ms, attn_ms = (float(x) for x in t.tolist())
 

@@ -51,9 +51,14 @@
 
 namespace nvk {
 
-constexpr int   kStepTokens = NVK_STEP_TOKENS; // tokens per wave per pipeline step
-constexpr int   kTokPerLane = kStepTokens / 4; // tokens each lane holds per step
-static_assert(kStepTokens % 4 == 0 && kStepTokens >= 4, "a step is whole token quads");
+// A pipeline step is kStepTokens tokens per wave: 4 token slots x kTokPerLane tokens each.
+static_assert(NVK_STEP_TOKENS % 4 == 0 && NVK_STEP_TOKENS >= 4, "a step is whole token quads");
+constexpr int kStepTokens = NVK_STEP_TOKENS; // tokens per wave per pipeline step
+constexpr int kTokPerLane = kStepTokens / 4; // tokens each lane holds per step
+// Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) for rows of up to 128 floats; 4 (one per SIMD,
+// the whole register file) for 256-float rows, whose q, accumulators and two tiles for all four q-heads
+// of a group need about 300 registers -- cheaper than reading K/V once per q-head pair.
+constexpr int wg_waves(int vpl) { return vpl >= 4 ? 4 : 8; }
 constexpr float kNegBig     = -1.0e30f; // running-max seed: finite, so exp2(m - m) never sees inf - inf
 // The reference seeds its max with -1e10 (attention.hpp:126); in the exp2
 // domain that floor is -1e10 * log2(e).
@@ -90,7 +95,10 @@ struct DecodeParams
     int             kv_mul; // n_heads / n_kv_heads
     int             head_dim;
     int             max_chunks;
-    float           q_scale; // log2(e) / sqrt(head_dim)
+    int             kv_waves;  // kv-heads (= waves along the kv axis) per workgroup; the workgroup's other
+                               // blockDim/64/kv_waves waves split the chunk's tokens among themselves
+    int             merge_off; // int offset of the token-split merge area behind the table slice in LDS
+    float           q_scale;   // log2(e) / sqrt(head_dim)
 };
 
 // ---- address arithmetic shared by decode, gather and append ---------------
@@ -261,10 +269,15 @@ __global__ void __launch_bounds__(kPlanThreads)
 // QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.y also walks kv_mul/QPK)
 // FULL  head_dim == 64*VPL, so no lane is idle and no load needs a predicate
 // grid: x = work item (upper bound; workgroups past *n_items leave), y = kv-head group x q sub-group
+// Waves: wave w owns kv-head (w % kv_waves) of the group; when the pool has fewer than 8 kv-heads
+// (a head-sharded rank, small models; fewer than 4 for 256-float rows) the remaining waves split the
+// chunk's tokens ("token-split"):
+// wave w takes sub-range w / kv_waves, and the sub-ranges are merged through LDS at the end, so a
+// workgroup keeps 8 waves of loads in flight whatever the head count.
 template <int VPL, int QPK, bool FULL>
-__global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(const DecodeParams p)
+__global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(const DecodeParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice
+    extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice (+ merge area)
 
     if ((int)blockIdx.x >= *p.n_items)
         return;
@@ -284,7 +297,9 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
     // blockIdx.y enumerates (kv-head group, q sub-group); waves enumerate kv-heads in the group
     const int  qsplit = p.kv_mul / QPK;
     const int  zq     = blockIdx.y % qsplit;
-    const int  kvh    = (blockIdx.y / qsplit) * nwaves + wave;
+    const int  parts  = nwaves / p.kv_waves; // token-split factor (1 when the group has 8 kv-heads)
+    const int  part   = wave / p.kv_waves;
+    const int  kvh    = (blockIdx.y / qsplit) * p.kv_waves + wave % p.kv_waves;
     const bool live   = kvh < p.n_kv_heads;
     const int  qh0    = kvh * p.kv_mul + zq * QPK; // first q-head of this wave
 
@@ -296,7 +311,7 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
 
     if (t1 <= t0) {
         // a sequence with no context: the reference zeroes `out` and does nothing else (attention.hpp:98)
-        if (live && slot == 0) {
+        if (live && slot == 0 && part == 0) {
 #pragma unroll
             for (int h = 0; h < QPK; h++)
 #pragma unroll
@@ -331,7 +346,16 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         s_tab[i] = clamp_block(p.block_tables[(int64_t)trow * p.max_blocks + blk0 + i], p.num_blocks);
     __syncthreads();
     if (!live)
-        return; // no barrier after this point
+        return; // dead waves exist only in groups of 8 kv-waves, which have no second barrier (parts == 1)
+
+    // this wave's share of the chunk: whole steps, contiguous
+    int w0 = t0, w1 = t1;
+    if (parts > 1) {
+        const int per = ((t1 - t0 + kStepTokens - 1) / kStepTokens + parts - 1) / parts * kStepTokens;
+        w0            = min(t1, t0 + part * per);
+        w1            = min(t1, w0 + per);
+    }
+    const bool has_tokens = w0 < w1;
 
     // pre-scale q into the exp2 domain
 #pragma unroll
@@ -360,7 +384,7 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++) {
             // lanes past the chunk's end (last step only) re-read its last row; consume_tile masks their scores
-            const int tok = min(ts + 4 * i + slot, t1 - 1);
+            const int tok = min(ts + 4 * i + slot, w1 - 1);
             const int blk = token_block(tok, p.bs_magic);
             const int off = token_offset(tok, blk, p.block_size);
             const int pb  = s_tab[blk - blk0];
@@ -390,7 +414,7 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
         float          s[kTokPerLane][QPK];
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++) {
-            const bool in_range = !TAIL || (ts + 4 * i + slot < t1);
+            const bool in_range = !TAIL || (ts + 4 * i + slot < w1);
 #pragma unroll
             for (int h = 0; h < QPK; h++) {
                 float acc = 0.f;
@@ -440,23 +464,25 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
     // or two steps (the only ones that can run past the chunk's end) are peeled off.
     const std::integral_constant<bool, false> body;
     const std::integral_constant<bool, true>  tail;
-    const int nsteps = (t1 - t0 + kStepTokens - 1) / kStepTokens;
-    KVTile<VPL> ta, tb;
-    int         k = 0;
-    load_tile(ta, t0);
-    for (; k + 2 < nsteps; k += 2) {
-        load_tile(tb, t0 + (k + 1) * kStepTokens);
-        consume_tile(ta, t0 + k * kStepTokens, body);
-        load_tile(ta, t0 + (k + 2) * kStepTokens);
-        consume_tile(tb, t0 + (k + 1) * kStepTokens, body);
-    }
-    if (nsteps - k == 2) {
-        load_tile(tb, t0 + (k + 1) * kStepTokens);
-        consume_tile(ta, t0 + k * kStepTokens, body);
-        consume_tile(tb, t0 + (k + 1) * kStepTokens, tail);
-    }
-    else {
-        consume_tile(ta, t0 + k * kStepTokens, tail);
+    if (has_tokens) {
+        const int   nsteps = (w1 - w0 + kStepTokens - 1) / kStepTokens;
+        KVTile<VPL> ta, tb;
+        int         k = 0;
+        load_tile(ta, w0);
+        for (; k + 2 < nsteps; k += 2) {
+            load_tile(tb, w0 + (k + 1) * kStepTokens);
+            consume_tile(ta, w0 + k * kStepTokens, body);
+            load_tile(ta, w0 + (k + 2) * kStepTokens);
+            consume_tile(tb, w0 + (k + 1) * kStepTokens, body);
+        }
+        if (nsteps - k == 2) {
+            load_tile(tb, w0 + (k + 1) * kStepTokens);
+            consume_tile(ta, w0 + k * kStepTokens, body);
+            consume_tile(tb, w0 + (k + 1) * kStepTokens, tail);
+        }
+        else {
+            consume_tile(ta, w0 + k * kStepTokens, tail);
+        }
     }
 
     // merge the four token slots of the wave (lanes 16 and 32 apart)
@@ -479,6 +505,55 @@ __global__ void __launch_bounds__(512, NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(c
             a.x += __shfl_xor(a.x, 32), a.y += __shfl_xor(a.y, 32), a.z += __shfl_xor(a.z, 32),
                 a.w += __shfl_xor(a.w, 32);
             o[h][j] = a;
+        }
+    }
+
+    // token-split: the workgroup's sub-ranges of one kv-head meet in LDS; part 0 carries on with the sum
+    if (parts > 1) {
+        constexpr int kRec = 4 + VPL * 64; // floats per (wave, q-head): m, l, pad, pad, then o as [VPL][16] float4
+        float        *s_mrg = reinterpret_cast<float *>(s_tab + p.merge_off);
+        if (slot == 0 && part > 0) {
+#pragma unroll
+            for (int h = 0; h < QPK; h++) {
+                float *rec = s_mrg + (wave * QPK + h) * kRec;
+                if (r == 0)
+                    rec[0] = m[h], rec[1] = l[h];
+#pragma unroll
+                for (int j = 0; j < VPL; j++)
+                    *reinterpret_cast<float4 *>(rec + 4 + (j * 16 + r) * 4) = o[h][j];
+            }
+        }
+        __syncthreads();
+        if (part > 0)
+            return;
+        if (slot == 0) {
+#pragma unroll
+            for (int h = 0; h < QPK; h++) {
+                float mw = m[h];
+                for (int q = 1; q < parts; q++)
+                    mw = fmaxf(mw, s_mrg[((q * p.kv_waves + wave) * QPK + h) * kRec]);
+                const float f0 = fast_exp2(m[h] - mw);
+                float       lw = l[h] * f0;
+                float4      a[VPL];
+#pragma unroll
+                for (int j = 0; j < VPL; j++)
+                    a[j] = make_float4(o[h][j].x * f0, o[h][j].y * f0, o[h][j].z * f0, o[h][j].w * f0);
+                for (int q = 1; q < parts; q++) {
+                    const float *rec = s_mrg + ((q * p.kv_waves + wave) * QPK + h) * kRec;
+                    const float  f   = fast_exp2(rec[0] - mw);
+                    lw               = fmaf(rec[1], f, lw);
+#pragma unroll
+                    for (int j = 0; j < VPL; j++) {
+                        const float4 b = *reinterpret_cast<const float4 *>(rec + 4 + (j * 16 + r) * 4);
+                        a[j].x = fmaf(b.x, f, a[j].x), a[j].y = fmaf(b.y, f, a[j].y);
+                        a[j].z = fmaf(b.z, f, a[j].z), a[j].w = fmaf(b.w, f, a[j].w);
+                    }
+                }
+                m[h] = mw, l[h] = lw;
+#pragma unroll
+                for (int j = 0; j < VPL; j++)
+                    o[h][j] = a[j];
+            }
         }
     }
 

@@ -176,7 +176,9 @@ struct LaunchShape
 {
     int chunk_tokens = 0; // multiple of kStepTokens
     int max_chunks   = 1;
-    int waves        = 1; // kv-heads per workgroup
+    int waves        = 1; // kv-heads per workgroup (waves along the kv axis)
+    int parts        = 1; // token-split factor: waves * parts waves per workgroup
+    int merge_off    = 0; // int offset of the token-split merge area in LDS
     int kv_groups    = 1;
     int qpk          = 1; // q-heads per wave
     int vpl          = 1;
@@ -199,10 +201,12 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     plan->vpl        = hd <= 64 ? 1 : (hd <= 128 ? 2 : 4);
     plan->full       = hd == 64 * plan->vpl;
     plan->qpk        = kv_mul % 4 == 0 ? 4 : (kv_mul % 2 == 0 ? 2 : 1);
-    if (plan->vpl == 4 && plan->qpk == 4)
-        plan->qpk = 2; // 4 q-heads x 16 floats of q and o per lane would spill
-    plan->waves      = std::min(pool->n_kv_heads, NVK_WG_WAVES);
+    const int wg_waves = std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl));
+    plan->waves      = std::min(pool->n_kv_heads, wg_waves);
     plan->kv_groups  = (pool->n_kv_heads + plan->waves - 1) / plan->waves;
+    // fewer kv-heads than a workgroup has waves (a head-sharded rank, a small model): the other waves split
+    // the chunk's tokens, so the workgroup still has all its waves' loads in flight
+    plan->parts      = plan->kv_groups == 1 ? std::max(1, wg_waves / plan->waves) : 1;
 
     const int step    = nvk::kStepTokens;
     const int ctx_cap = round_up(std::max(max_ctx, 1), step);
@@ -236,7 +240,10 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
                          plan->chunk_tokens, max_ctx);
     if ((unsigned long long)max_ctx * (unsigned)pool->block_size >= (1ULL << 32))
         return nvk::fail(NVK_ERR_INVALID_ARG, "max_ctx=%d too long for block_size=%d", max_ctx, pool->block_size);
-    plan->lds_bytes    = ((size_t)plan->chunk_tokens / pool->block_size + 2) * sizeof(int);
+    plan->merge_off    = (plan->chunk_tokens / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
+    plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int);
+    if (plan->parts > 1)
+        plan->lds_bytes += (size_t)plan->waves * plan->parts * plan->qpk * (4 + plan->vpl * 64) * sizeof(float);
     return NVK_OK;
 }
 
@@ -254,11 +261,7 @@ template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, d
                                                 const nvk::DecodeParams &p)
 {
     switch (qpk) {
-    case 4:
-        if constexpr (VPL < 4) // <4,4> would spill; make_plan never asks for it
-            return launch_decode_full<VPL, 4>(full, grid, block, lds, stream, p);
-        else
-            return hipErrorInvalidValue;
+    case 4: return launch_decode_full<VPL, 4>(full, grid, block, lds, stream, p);
     case 2: return launch_decode_full<VPL, 2>(full, grid, block, lds, stream, p);
     default: return launch_decode_full<VPL, 1>(full, grid, block, lds, stream, p);
     }
@@ -394,10 +397,12 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     p.kv_mul       = kv_mul;
     p.head_dim     = pool->head_dim;
     p.max_chunks   = sh.max_chunks;
+    p.kv_waves     = sh.waves;
+    p.merge_off    = sh.merge_off;
     p.q_scale      = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
 
     const dim3 grid((unsigned)plan->item_bound, (unsigned)(sh.kv_groups * (kv_mul / sh.qpk)));
-    const dim3 block((unsigned)sh.waves * 64);
+    const dim3 block((unsigned)(sh.waves * sh.parts) * 64);
     if (ev_attn_begin)
         HIP_TRY(hipEventRecord(ev_attn_begin, stream));
     HIP_TRY(launch_decode(sh, grid, block, stream, p));

@@ -3,7 +3,9 @@
 The reference is single-process; its attention touches one table, one q and
 one out per sequence (``include/core/attention.hpp:82-159``) with the q-head loop
 outermost (``:102``) and kv-head ``h / kv_mul`` (``:105``), so a batch splits two ways
-without changing a single output bit:
+without changing the result (bit for bit by sequence; by head group up to the
+association of fp32 sums, because a shard with few kv-heads spreads each chunk's
+tokens over its spare waves):
 
 * by **sequence** -- rank r owns a private pool, block manager and batch; nothing
   is exchanged (:func:`partition_sequences`, :func:`contiguous_ranges`; no collective);

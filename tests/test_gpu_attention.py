@@ -358,10 +358,12 @@ def test_many_sequences_cross_plan_tiles():
             assert not got[ctx == 0].any()
 
 
-def test_head_sharded_pools_reproduce_the_full_result_bitwise():
+def test_head_sharded_pools_reproduce_the_full_result():
     """SURVEY.md 8e, head-sharded variant, emulated on one GPU: G pools of n_kv_heads/G kv-heads each, the rank
-    slices of q, and the gathered layout [G, n, H/G, hd] assembled back -- every bit equal to the one-pool result
-    (the all-gather itself is covered over gloo in tests/test_sharding_gloo.py)."""
+    slices of q, and the gathered layout [G, n, H/G, hd] assembled back, against the one-pool result and the
+    checker (the all-gather itself is covered over gloo in tests/test_sharding_gloo.py).  A shard with fewer
+    than 8 kv-heads splits each chunk's tokens over its spare waves, so sums are associated differently from
+    the one-pool run: equal to a few ulp, not bit for bit."""
     from nano_vllm_amd import sharding as sh
 
     g = wl.Geometry(16, 8, 128, 16)
@@ -381,7 +383,10 @@ def test_head_sharded_pools_reproduce_the_full_result_bitwise():
                     pool.upload_block(0, b, hs.local_kv_block(k_host[b]), hs.local_kv_block(v_host[b]))
                 parts.append(nv.decode(pool, 0, hs.local_q(q), tabs, c, nv.SPLIT_K, 512))
         got = sh.assemble_heads(np.stack(parts))
-        assert np.array_equal(got.view(np.uint32), full.view(np.uint32)), world
+        assert_close(got, full, f"world {world}")
+        assert np.abs(got - full).max() <= 2e-6
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, g.block_size, g.n_kv_heads)
+    assert_close(got, want, "vs checker")
 
 
 @pytest.mark.parametrize("geom", [(6, 6, 48, 16), (32, 8, 128, 16), (8, 2, 64, 32), (4, 4, 20, 8)],
