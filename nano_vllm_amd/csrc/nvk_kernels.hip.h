@@ -53,8 +53,11 @@ namespace nvk {
 
 // A pipeline step is kStepTokens tokens per wave: 4 token slots x kTokPerLane tokens each.
 static_assert(NVK_STEP_TOKENS % 4 == 0 && NVK_STEP_TOKENS >= 4, "a step is whole token quads");
-constexpr int kStepTokens = NVK_STEP_TOKENS; // tokens per wave per pipeline step
-constexpr int kTokPerLane = kStepTokens / 4; // tokens each lane holds per step
+#ifndef NVK_TPL_VPL1
+#define NVK_TPL_VPL1 4 // tokens per lane per step for rows of <= 64 floats (twice the others: same bytes in flight)
+#endif
+constexpr int tok_per_lane(int vpl) { return vpl == 1 ? NVK_TPL_VPL1 : NVK_STEP_TOKENS / 4; }
+constexpr int step_tokens(int vpl) { return 4 * tok_per_lane(vpl); }
 // Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) for rows of up to 128 floats; 4 (one per SIMD,
 // the whole register file) for 256-float rows, whose q, accumulators and two tiles for all four q-heads
 // of a group need about 300 registers -- cheaper than reading K/V once per q-head pair.
@@ -149,8 +152,8 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b, float ac
 
 template <int VPL> struct KVTile
 {
-    float4 k[kTokPerLane][VPL];
-    float4 v[kTokPerLane][VPL];
+    float4 k[tok_per_lane(VPL)][VPL];
+    float4 v[tok_per_lane(VPL)][VPL];
 };
 
 __device__ __forceinline__ float4 load_kv(const float *p)
@@ -277,6 +280,8 @@ __global__ void __launch_bounds__(kPlanThreads)
 template <int VPL, int QPK, bool FULL>
 __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(const DecodeParams p)
 {
+    constexpr int kTokPerLane = tok_per_lane(VPL); // tokens each lane holds per step
+    constexpr int kStepTokens = step_tokens(VPL);  // tokens per wave per pipeline step
     extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice (+ merge area)
 
     if ((int)blockIdx.x >= *p.n_items)

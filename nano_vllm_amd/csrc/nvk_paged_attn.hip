@@ -208,7 +208,7 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     // the chunk's tokens, so the workgroup still has all its waves' loads in flight
     plan->parts      = plan->kv_groups == 1 ? std::max(1, wg_waves / plan->waves) : 1;
 
-    const int step    = nvk::kStepTokens;
+    const int step    = nvk::step_tokens(plan->vpl);
     const int ctx_cap = round_up(std::max(max_ctx, 1), step);
     // a workgroup stages its chunk's table slice in LDS: bound the chunk by that
     const long long slice_cap = (long long)kMaxTableSliceEntries * pool->block_size / step * step;
