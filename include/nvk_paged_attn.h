@@ -235,6 +235,20 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
  * through the same kernels behind an identity block table.  att_scores ignored. */
 int nvk_standard_attention(float *out, const float *q, const float *key_cache, const float *value_cache,
                            float *att_scores, int pos, int head_dim, int n_heads, int n_kv_heads, int max_seq_len);
+/* How the host-slab forms of the two drop-in entry points bring K/V to the device (per thread).
+ *  NVK_HOST_CACHE_RESTAGE (default): every call copies the rows it reads; always correct.
+ *  NVK_HOST_CACHE_APPEND_ONLY: the caller promises what the reference engine does -- between two calls
+ *    for the same slab, rows are only appended (include/core/model.hpp:190-207,211-217) and num_tokens
+ *    grows by one (:397).  A device mirror per slab (keyed by the key_cache pointer) then keeps what it
+ *    has, and only new rows cross PCIe: 2 rows per call instead of 2 * num_tokens.  A call that is not
+ *    "the previous call on this slab plus one token" restages everything, so a new request needs no
+ *    notice; rewriting rows in place between such calls is what the promise forbids.
+ * Switching back to RESTAGE frees the mirrors.  nvk_host_cache_staged_bytes: K/V bytes the drop-in
+ * entry points have copied host-to-device on this thread (reset != 0 clears the counter). */
+#define NVK_HOST_CACHE_RESTAGE 0
+#define NVK_HOST_CACHE_APPEND_ONLY 1
+int       nvk_set_host_cache_policy(int policy);
+long long nvk_host_cache_staged_bytes(int reset);
 /* Bind (pool, layer) as this thread's cache for nvk_paged_attention; pool NULL unbinds.
  * ref: the layer slicing in LlamaModel::attention, include/core/model.hpp:400-403. */
 int nvk_bind_pool(nvk_pool *pool, int layer);

@@ -8,7 +8,7 @@ hyphen is not importable in Python.)
 """
 from . import _capi
 from ._capi import NvkError, device_count, version
-from .attention import AUTO, SINGLE_PASS, SPLIT_K, DecodePlan, bind_pool, decode, decode_bench, decode_device, paged_attention, standard_attention
+from .attention import AUTO, SINGLE_PASS, SPLIT_K, DecodePlan, bind_pool, decode, decode_bench, decode_device, host_cache_staged_bytes, paged_attention, set_host_cache_policy, standard_attention
 from .batch import DecodeBatch
 from .block_manager import BlockManager
 from .kv_pool import PagedKVPool
@@ -16,5 +16,5 @@ from .prefill import PREFILL_AUTO, PREFILL_ROWWISE, PREFILL_TILED, prefill, pref
 
 __all__ = [
     "AUTO", "PREFILL_AUTO", "PREFILL_ROWWISE", "PREFILL_TILED", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "NvkError", "PagedKVPool", "bind_pool", "decode",
-    "decode_bench", "decode_device", "device_count", "paged_attention", "prefill", "prefill_device", "rope_append_chunks", "standard_attention", "version",
+    "decode_bench", "decode_device", "device_count", "host_cache_staged_bytes", "paged_attention", "prefill", "prefill_device", "rope_append_chunks", "set_host_cache_policy", "standard_attention", "version",
 ]

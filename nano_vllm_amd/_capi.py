@@ -28,6 +28,9 @@ PREFILL_AUTO = 0
 PREFILL_ROWWISE = 1
 PREFILL_TILED = 2
 
+HOST_CACHE_RESTAGE = 0
+HOST_CACHE_APPEND_ONLY = 1
+
 PTR_HOST = 0
 PTR_DEVICE = 1
 
@@ -94,6 +97,8 @@ SIGNATURES = {
     "nvk_decode_planned": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "nvk_paged_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nvk_standard_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "nvk_set_host_cache_policy": (C.c_int, [C.c_int]),
+    "nvk_host_cache_staged_bytes": (C.c_longlong, [C.c_int]),
     "nvk_bind_pool": (C.c_int, [_vp, C.c_int]),
     "nvk_batch_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "nvk_batch_destroy": (C.c_int, [_vp]),

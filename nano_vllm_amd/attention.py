@@ -31,6 +31,18 @@ def bind_pool(pool: Optional[PagedKVPool], layer: int = 0) -> None:
     _capi.check(_capi.lib.nvk_bind_pool(pool.handle if pool is not None else None, int(layer)))
 
 
+def set_host_cache_policy(append_only: bool) -> None:
+    """How the host-slab forms of :func:`paged_attention` / :func:`standard_attention` stage K/V:
+    re-stage every call (default, always correct) or keep a device mirror per slab under the promise that
+    the engine only appends rows between calls, as ``LlamaModel::forward`` does (``model.hpp:190-207``)."""
+    _capi.check(_capi.lib.nvk_set_host_cache_policy(_capi.HOST_CACHE_APPEND_ONLY if append_only
+                                                    else _capi.HOST_CACHE_RESTAGE))
+
+
+def host_cache_staged_bytes(reset: bool = False) -> int:
+    return int(_capi.lib.nvk_host_cache_staged_bytes(1 if reset else 0))
+
+
 def paged_attention(out: np.ndarray, q, key_cache, value_cache, block_table, att_scores, num_tokens: int,
                     block_size: int, head_dim: int, n_heads: int, n_kv_heads: int) -> None:
     """Drop-in for ``Attention::paged_attention`` (same eleven arguments, same meaning).

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "nvk_internal.h"
@@ -614,9 +615,98 @@ int scratch_pool_for(int block_size, int n_kv_heads, int head_dim, int nblk, nvk
     return NVK_OK;
 }
 
+// ---- host-slab mirrors (NVK_HOST_CACHE_APPEND_ONLY) --------------------------
+// The drop-in entry points get the engine's HOST slabs.  Re-staging the whole context on every call
+// is always correct and PCIe-bound; but the reference engine only ever appends: between two calls
+// for the same slab exactly one new token row is written (model.hpp:190-207) and num_tokens grows by
+// one (model.hpp:397).  Under that promise a device mirror per slab keeps what it has and only the
+// rows it has not seen cross PCIe.  Any call that is not "the previous call plus one token" on the
+// same slab restages everything, so a new request (pos back to 0) is handled without being told.
+struct HostMirror
+{
+    const float *k_host = nullptr, *v_host = nullptr;
+    nvk_pool    *pool   = nullptr; // one layer; local block ids
+    int          last_tokens = -1;
+    bool         contiguous  = false; // mirror of a contiguous cache (nvk_standard_attention): one row counter
+    std::unordered_map<int, int> local_of; // physical block id of the host slab -> block of `pool`
+    std::vector<int>             rows_staged; // per local block
+};
+thread_local std::vector<HostMirror> t_mirrors;
+thread_local int                     t_host_policy = NVK_HOST_CACHE_RESTAGE;
+thread_local long long               t_staged_bytes = 0; // H2D bytes of K/V rows moved by the drop-in entry points
+
+void drop_mirror(HostMirror &m)
+{
+    if (m.pool)
+        nvk_pool_destroy(m.pool);
+    m = HostMirror();
+}
+
+// Finds or creates the mirror of (key_cache, value_cache) with room for `need_blocks` blocks.
+int mirror_for(const float *key_cache, const float *value_cache, int block_size, int n_kv_heads, int head_dim,
+               int need_blocks, bool contiguous, HostMirror **out)
+{
+    HostMirror *hit = nullptr;
+    for (HostMirror &m : t_mirrors)
+        if (m.k_host == key_cache)
+            hit = &m;
+    if (hit
+        && (hit->v_host != value_cache || hit->contiguous != contiguous || hit->pool->block_size != block_size || hit->pool->n_kv_heads != n_kv_heads
+            || hit->pool->head_dim != head_dim || hit->pool->num_blocks < need_blocks)) {
+        drop_mirror(*hit); // geometry changed or it has outgrown its pool: start over (everything restaged)
+        hit->k_host = nullptr;
+    }
+    if (!hit || !hit->pool) {
+        const bool fresh = !hit;
+        if (!hit) {
+            if (t_mirrors.size() >= 256) { // a bound on what one thread may pin: recycle the oldest
+                drop_mirror(t_mirrors.front());
+                t_mirrors.erase(t_mirrors.begin());
+            }
+            t_mirrors.emplace_back();
+            hit = &t_mirrors.back();
+        }
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess)
+            dev = 0;
+        int rc = nvk_pool_create(1, std::max(2 * need_blocks, 64), block_size, n_kv_heads, head_dim, dev, &hit->pool);
+        if (rc != NVK_OK) {
+            if (fresh)
+                t_mirrors.pop_back();
+            return rc;
+        }
+        hit->k_host = key_cache, hit->v_host = value_cache, hit->last_tokens = -1, hit->contiguous = contiguous;
+        hit->local_of.clear();
+        hit->rows_staged.clear();
+    }
+    *out = hit;
+    return NVK_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int nvk_set_host_cache_policy(int policy)
+{
+    if (policy != NVK_HOST_CACHE_RESTAGE && policy != NVK_HOST_CACHE_APPEND_ONLY)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_set_host_cache_policy: policy %d", policy);
+    if (policy == NVK_HOST_CACHE_RESTAGE) {
+        for (HostMirror &m : t_mirrors)
+            drop_mirror(m);
+        t_mirrors.clear();
+    }
+    t_host_policy = policy;
+    return NVK_OK;
+}
+
+long long nvk_host_cache_staged_bytes(int reset)
+{
+    const long long v = t_staged_bytes;
+    if (reset)
+        t_staged_bytes = 0;
+    return v;
+}
 
 const char *nvk_version(void) { return NVK_VERSION_STRING; }
 const char *nvk_last_error(void) { return nvk::g_last_error; }
@@ -1505,22 +1595,67 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
         std::memset(out, 0, (size_t)n_heads * head_dim * sizeof(float));
         return NVK_OK;
     }
+    for (int i = 0; i < nblk; i++)
+        if (block_table[i] < 0)
+            return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_paged_attention: block_table[%d]=%d is negative", i, block_table[i]);
+    const size_t     row = (size_t)n_kv_heads * head_dim;
+    const size_t     blk = (size_t)block_size * row;
+    std::vector<int> local((size_t)nblk);
+
+    if (t_host_policy == NVK_HOST_CACHE_APPEND_ONLY) {
+        HostMirror *m  = nullptr;
+        int         rc = mirror_for(key_cache, value_cache, block_size, n_kv_heads, head_dim, nblk, false, &m);
+        if (rc != NVK_OK)
+            return rc;
+        nvk_pool   *mp = m->pool;
+        DeviceScope scope(mp->device);
+        if (num_tokens != m->last_tokens + 1) // not "the previous call plus one token": trust nothing staged
+            std::fill(m->rows_staged.begin(), m->rows_staged.end(), 0);
+        for (int i = 0; i < nblk; i++) {
+            auto it = m->local_of.find(block_table[i]);
+            if (it == m->local_of.end()) {
+                if ((int)m->rows_staged.size() >= mp->num_blocks) { // more distinct blocks than the mirror holds
+                    m->local_of.clear();
+                    m->rows_staged.clear();
+                    m->last_tokens = -1;
+                    return nvk_paged_attention(out, q, key_cache, value_cache, block_table, att_scores, num_tokens,
+                                               block_size, head_dim, n_heads, n_kv_heads); // remapped from scratch
+                }
+                it = m->local_of.emplace(block_table[i], (int)m->rows_staged.size()).first;
+                m->rows_staged.push_back(0);
+            }
+            const int lb     = it->second;
+            const int filled = std::min(block_size, num_tokens - i * block_size);
+            int      &have   = m->rows_staged[(size_t)lb];
+            if (have < filled) {
+                const size_t at = (size_t)have * row, n = (size_t)(filled - have) * row;
+                HIP_TRY(hipMemcpyAsync(mp->k_layer(0) + (size_t)lb * blk + at, key_cache + (size_t)block_table[i] * blk + at,
+                                       n * sizeof(float), hipMemcpyHostToDevice, mp->stream));
+                HIP_TRY(hipMemcpyAsync(mp->v_layer(0) + (size_t)lb * blk + at,
+                                       value_cache + (size_t)block_table[i] * blk + at, n * sizeof(float),
+                                       hipMemcpyHostToDevice, mp->stream));
+                t_staged_bytes += (long long)(2 * n * sizeof(float));
+                have = filled;
+            }
+            local[(size_t)i] = lb;
+        }
+        m->last_tokens = num_tokens;
+        return nvk_decode(mp, 0, 1, n_heads, q, local.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
+    }
+
     nvk_pool *sp = nullptr;
     int       rc = scratch_pool_for(block_size, n_kv_heads, head_dim, nblk, &sp);
     if (rc != NVK_OK)
         return rc;
-    DeviceScope      scope(sp->device);
-    const size_t     blk = (size_t)block_size * n_kv_heads * head_dim;
-    std::vector<int> local((size_t)nblk);
+    DeviceScope scope(sp->device);
     for (int i = 0; i < nblk; i++) {
-        if (block_table[i] < 0)
-            return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_paged_attention: block_table[%d]=%d is negative", i, block_table[i]);
         // only the rows of the block that the sequence has reached (the last block is partly filled)
-        const size_t rows = (size_t)std::min(block_size, num_tokens - i * block_size) * n_kv_heads * head_dim;
+        const size_t rows = (size_t)std::min(block_size, num_tokens - i * block_size) * row;
         HIP_TRY(hipMemcpyAsync(sp->k_layer(0) + (size_t)i * blk, key_cache + (size_t)block_table[i] * blk,
                                rows * sizeof(float), hipMemcpyHostToDevice, sp->stream));
         HIP_TRY(hipMemcpyAsync(sp->v_layer(0) + (size_t)i * blk, value_cache + (size_t)block_table[i] * blk,
                                rows * sizeof(float), hipMemcpyHostToDevice, sp->stream));
+        t_staged_bytes += (long long)(2 * rows * sizeof(float));
         local[(size_t)i] = i;
     }
     return nvk_decode(sp, 0, 1, n_heads, q, local.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
@@ -1543,17 +1678,45 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
     constexpr int kBlock     = 16;
     const int     num_tokens = pos + 1;
     const int     nblk       = (num_tokens + kBlock - 1) / kBlock;
-    nvk_pool     *sp         = nullptr;
-    int           rc         = scratch_pool_for(kBlock, n_kv_heads, head_dim, nblk, &sp);
-    if (rc != NVK_OK)
-        return rc;
-    DeviceScope  scope(sp->device);
-    const size_t bytes = (size_t)num_tokens * n_kv_heads * head_dim * sizeof(float);
-    HIP_TRY(hipMemcpyAsync(sp->k_layer(0), key_cache, bytes, hipMemcpyHostToDevice, sp->stream));
-    HIP_TRY(hipMemcpyAsync(sp->v_layer(0), value_cache, bytes, hipMemcpyHostToDevice, sp->stream));
     std::vector<int> ident((size_t)nblk);
     for (int i = 0; i < nblk; i++)
         ident[(size_t)i] = i;
+    const size_t row = (size_t)n_kv_heads * head_dim;
+
+    if (t_host_policy == NVK_HOST_CACHE_APPEND_ONLY) {
+        // the contiguous cache only grows at its end (model.hpp:211-217): keep rows [0, staged) on the device
+        HostMirror *m  = nullptr;
+        int         rc = mirror_for(key_cache, value_cache, kBlock, n_kv_heads, head_dim, nblk, true, &m);
+        if (rc != NVK_OK)
+            return rc;
+        DeviceScope scope(m->pool->device);
+        if (m->rows_staged.empty())
+            m->rows_staged.push_back(0); // one counter: rows of the contiguous cache already on the device
+        int &have = m->rows_staged[0];
+        if (num_tokens != m->last_tokens + 1)
+            have = 0;
+        if (have < num_tokens) {
+            const size_t at = (size_t)have * row, n = (size_t)(num_tokens - have) * row;
+            HIP_TRY(hipMemcpyAsync(m->pool->k_layer(0) + at, key_cache + at, n * sizeof(float), hipMemcpyHostToDevice,
+                                   m->pool->stream));
+            HIP_TRY(hipMemcpyAsync(m->pool->v_layer(0) + at, value_cache + at, n * sizeof(float), hipMemcpyHostToDevice,
+                                   m->pool->stream));
+            t_staged_bytes += (long long)(2 * n * sizeof(float));
+            have = num_tokens;
+        }
+        m->last_tokens = num_tokens;
+        return nvk_decode(m->pool, 0, 1, n_heads, q, ident.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
+    }
+
+    nvk_pool *sp = nullptr;
+    int       rc = scratch_pool_for(kBlock, n_kv_heads, head_dim, nblk, &sp);
+    if (rc != NVK_OK)
+        return rc;
+    DeviceScope  scope(sp->device);
+    const size_t bytes = (size_t)num_tokens * row * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(sp->k_layer(0), key_cache, bytes, hipMemcpyHostToDevice, sp->stream));
+    HIP_TRY(hipMemcpyAsync(sp->v_layer(0), value_cache, bytes, hipMemcpyHostToDevice, sp->stream));
+    t_staged_bytes += (long long)(2 * bytes);
     return nvk_decode(sp, 0, 1, n_heads, q, ident.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
 }
 

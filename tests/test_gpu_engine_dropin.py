@@ -87,3 +87,54 @@ def test_reference_engine_with_drop_in(engine, spec, paged, golden_dir):
             stream.append(tok)
         engine.ref_model_destroy(m)
         assert stream == gold[n + "/greedy_stream"].tolist()
+
+
+@pytest.mark.parametrize("paged", [1, 0], ids=["paged", "contiguous"])
+def test_append_only_host_cache_policy_same_stream_far_less_pcie(engine, paged, golden_dir):
+    """NVK_HOST_CACHE_APPEND_ONLY: the engine's host slabs are mirrored on the device and only new rows are
+    copied.  Same token stream as the recorded reference run; K/V bytes over PCIe drop from O(T^2) to O(T);
+    a second request on the same model (pos back to 0) is noticed without being announced."""
+    import nano_vllm_amd as nv
+
+    spec = TINY_MODELS[1]
+    gold = np.load(os.path.join(golden_dir, "tiny_llama_stream.npz"))
+    n, vocab = spec["name"], spec["vocab_size"]
+    logits = np.empty(vocab, np.float32)
+
+    def greedy(m):
+        prompt, pos = spec["prompt_tokens"], 0
+        for tok in prompt[:-1]:
+            assert engine.ref_model_forward(m, int(tok), pos, None) == 0
+            pos += 1
+        tok, stream = int(prompt[-1]), []
+        for _ in range(spec["gen_steps"]):
+            assert engine.ref_model_forward(m, tok, pos, _p(logits)) == 0
+            pos += 1
+            tok = int(engine.ref_greedy_sample(_p(logits), vocab))
+            stream.append(tok)
+        return stream, pos
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "model.bin")
+        write_checkpoint(path, spec)
+        staged = {}
+        for append_only in (False, True):
+            nv.set_host_cache_policy(append_only)
+            try:
+                nv.host_cache_staged_bytes(reset=True)
+                m = engine.ref_model_create(path.encode(), paged, spec["block_size"], spec["num_blocks"])
+                stream, n_tok = greedy(m)
+                assert stream == gold[n + "/greedy_stream"].tolist(), append_only
+                staged[append_only] = nv.host_cache_staged_bytes(reset=True)
+                engine.ref_model_destroy(m)
+                if append_only:  # a fresh model very likely reuses the freed slabs' addresses: must not see stale rows
+                    m = engine.ref_model_create(path.encode(), paged, spec["block_size"], spec["num_blocks"])
+                    stream2, _ = greedy(m)
+                    assert stream2 == gold[n + "/greedy_stream"].tolist()
+                    engine.ref_model_destroy(m)
+            finally:
+                nv.set_host_cache_policy(False)
+        row_bytes = spec["n_kv_heads"] * (spec["dim"] // spec["n_heads"]) * 4
+        L = spec["n_layers"]
+        assert staged[True] == 2 * row_bytes * n_tok * L  # every K and V row crossed PCIe exactly once
+        assert staged[False] == 2 * row_bytes * L * n_tok * (n_tok + 1) // 2  # the whole context on every call
