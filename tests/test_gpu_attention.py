@@ -448,3 +448,29 @@ def test_rope_append_then_decode_like_a_batched_model_step():
                 host_k[pb, t % bs], host_v[pb, t % bs] = wk, v[s]
                 want = ol.oracle_paged_attention(wq, host_k, host_v, tabs[s], t + 1, bs, hd, H, KV)
                 assert_close(got[s], want, f"step {t} seq {s}")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometry_batches_against_checker(seed):
+    """Differential sweep: random head geometry (every VPL / QPK / token-split / kv-group combination), block size,
+    ragged lengths and fragmented tables, each in auto, single-pass and a random split-K chunking."""
+    d = wl.splitmix64(4200 + seed, np.arange(12, dtype=np.uint64)).tolist()
+    KV = [1, 2, 3, 4, 5, 6, 8, 12, 16][d[0] % 9]
+    H = KV * [1, 2, 3, 4, 8][d[1] % 5]
+    hd = [4, 16, 20, 48, 64, 80, 96, 128, 132, 192, 256][d[2] % 11]
+    bs = [1, 4, 8, 12, 16, 32][d[3] % 6]
+    n = 1 + d[4] % 9
+    top = [40, 300, 1500][d[5] % 3]
+    ctx = (wl.splitmix64(seed, np.arange(n, dtype=np.uint64)) % np.uint64(top)).astype(np.int32)
+    ctx[d[6] % n] = top  # at least one sequence at the top of the range
+    g = wl.Geometry(H, KV, hd, bs)
+    work = wl.fragmented_workload(f"fuzz{seed}", ctx, g, slack=0.3, perm_seed=99 + seed)
+    q = work.q() * np.float32(1 + d[7] % 5)
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(n)))
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, bs, KV, n_threads=4)
+    chunk = [8, 24, 64, 200, 512][d[8] % 5]
+    with nv.PagedKVPool(1, work.num_blocks, bs, KV, hd) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for flags, ch in ((nv.AUTO, 0), (nv.SINGLE_PASS, 0), (nv.SPLIT_K, chunk)):
+            got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, flags, ch)
+            assert_close(got, want, f"H{H} KV{KV} hd{hd} bs{bs} ctx{ctx.tolist()} flags={flags} chunk={ch}")

@@ -104,3 +104,33 @@ def test_chunk_append_then_prefill_equals_token_by_token_decode():
             ka, va = a.download_block(0, pb)
             kb, vb = b.download_block(0, pb)
             assert np.array_equal(ka.view(np.uint32), kb.view(np.uint32)) and np.array_equal(va, vb)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_geometry_prefill_against_checker(seed):
+    """Differential sweep of the prefill forms over head geometry, block size, starts and chunk lengths."""
+    d = wl.splitmix64(5200 + seed, np.arange(12, dtype=np.uint64)).tolist()
+    KV = [1, 2, 3, 4, 6, 8][d[0] % 6]
+    H = KV * [1, 2, 3, 4, 8][d[1] % 5]
+    hd = [16, 20, 48, 64, 80, 128][d[2] % 6]
+    bs = [4, 8, 16, 32][d[3] % 4]
+    n = 1 + d[4] % 4
+    starts = (wl.splitmix64(seed, np.arange(n, dtype=np.uint64)) % np.uint64(200)).astype(np.int32)
+    lens = (wl.splitmix64(70 + seed, np.arange(n, dtype=np.uint64)) % np.uint64(150)).astype(np.int32)
+    lens[d[5] % n] = 1 + d[6] % 140
+    g = wl.Geometry(H, KV, hd, bs)
+    work = wl.fragmented_workload(f"pfuzz{seed}", starts + lens, g, slack=0.3, perm_seed=7 + seed)
+    k_host, v_host, tabs, _ = wl.host_blocks_for(work, list(range(n)))
+    total = int(lens.sum())
+    q = wl.uniform(900 + seed, 0, total * H * hd).reshape(total, H, hd) * np.float32(1 + d[7] % 4)
+    want = np.empty_like(q)
+    r = 0
+    for s in range(n):
+        if lens[s]:
+            want[r:r + lens[s]] = ol.oracle_paged_prefill(q[r:r + lens[s]], k_host, v_host, tabs[s], int(starts[s]), bs, KV)
+        r += int(lens[s])
+    with nv.PagedKVPool(1, work.num_blocks, bs, KV, hd) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for flags in MODES:
+            got = nv.prefill(pool, 0, q, work.block_tables, starts, lens, flags)
+            assert_close(got, want, f"H{H} KV{KV} hd{hd} bs{bs} starts{starts.tolist()} lens{lens.tolist()} flags={flags}")
