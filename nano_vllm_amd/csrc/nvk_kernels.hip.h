@@ -604,12 +604,12 @@ __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict_
                                                         const int *__restrict__ seq_chunks, float *__restrict__ out,
                                                         int n_heads, int head_dim, int max_chunks)
 {
-    const int seq = blockIdx.y;
+    const int seq = blockIdx.x; // rows on x: no 65535 limit on the batch
     const int nch = min(seq_chunks[seq], max_chunks);
     if (nch <= 1)
         return;
     const int vec_row = head_dim >> 2; // float4 per head
-    const int idx     = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx     = blockIdx.y * blockDim.x + threadIdx.x;
     if (idx >= n_heads * vec_row)
         return;
     const int head = idx / vec_row;
@@ -705,12 +705,18 @@ __global__ void nvk_append_kernel(float *__restrict__ k_layer, float *__restrict
 //     at the end (as in nvk_decode_kernel).  Keys past a query's position are masked to -inf
 //     only in the tiles that straddle the diagonal.
 //   * next K/V tile is fetched global -> registers while the current one is consumed.
+//   * split-K: when a call has too few (tile, head-group) pairs to fill the chip (one long prompt fed in
+//     chunks), the host cuts every tile's key range into parts; each part is an item that writes an
+//     unnormalised (m, l, o) partial per query row, combined by nvk_merge_kernel exactly as decode chunks are.
 // Bound: fp32 MFMA (64 FLOP/clk/SIMD); 128 MFMAs of 64 cycles per wave per 32x32 tile at HDP = 128.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct __attribute__((aligned(16))) PrefillItem
 {
     int seq, row0, pos0, nq; // table row, first packed q/out row, position of that query, queries in the tile
+    int k0, k1;              // keys [k0, k1) of the context are this item's share (k0 a multiple of 32)
+    int part, nparts;        // nparts > 1: the tile's key range is split over several items ("split-K"); each
+                             // writes an unnormalised partial and nvk_merge_kernel combines them
 };
 
 struct PrefillParams
@@ -719,6 +725,8 @@ struct PrefillParams
     const int         *block_tables;
     const PrefillItem *items;
     float             *out;
+    float             *ws_o, *ws_ml; // split-K partials: [row, max_parts, n_heads, head_dim] and [.., 2]
+    int                max_parts;
     int                max_blocks, num_blocks, block_size;
     unsigned           bs_magic;
     int                n_kv_heads, n_heads, kv_mul, head_dim;
@@ -752,12 +760,14 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
     const bool q_live = j < my_nq;
     const int qpos   = q_live ? item.pos0 + wq0 + j : 0x7fffffff; // dead lanes mask nothing, store nothing
     const int hd     = p.head_dim;
-    const int kmax   = item.pos0 + item.nq - 1;      // last key any query of the item sees
+    const int kbeg   = item.k0;                                    // first key of this item's share
+    const int kmax   = min(item.k1, item.pos0 + item.nq) - 1;      // last one (no query of the tile sees further)
     const int row_len = p.n_kv_heads * hd;
 
-    const int nblk = token_block(kmax, p.bs_magic) + 1;
+    const int blk0 = token_block(kbeg, p.bs_magic);
+    const int nblk = token_block(kmax, p.bs_magic) - blk0 + 1;
     for (int i = tid; i < nblk; i += 256)
-        s_tab[i] = clamp_block(p.block_tables[(int64_t)item.seq * p.max_blocks + i], p.num_blocks);
+        s_tab[i] = clamp_block(p.block_tables[(int64_t)item.seq * p.max_blocks + blk0 + i], p.num_blocks);
 
     // this wave's Q fragment: lane (query j, half) holds dims [half*HDP/2, (half+1)*HDP/2), pre-scaled
     float qf[HDP / 2];
@@ -786,7 +796,7 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
             if (tok <= kmax && 4 * c4 < hd) {
                 const int     blk = token_block(tok, p.bs_magic);
                 const int     off = token_offset(tok, blk, p.block_size);
-                const int64_t at  = ((int64_t)s_tab[blk] * p.block_size + off) * row_len + kvh * hd + 4 * c4;
+                const int64_t at  = ((int64_t)s_tab[blk - blk0] * p.block_size + off) * row_len + kvh * hd + 4 * c4;
                 kreg[u]           = *reinterpret_cast<const float4 *>(p.k_layer + at);
                 vreg[u]           = *reinterpret_cast<const float4 *>(p.v_layer + at);
             }
@@ -810,13 +820,13 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
         for (int r = 0; r < 16; r++)
             o[c][r] = 0.f;
 
-    const int ntiles    = kmax / 32 + 1;
+    const int ntiles    = (kmax - kbeg) / 32 + 1;
     const int wave_last = item.pos0 + wq0 + my_nq - 1; // last position this wave's queries reach
-    fetch_tile(0);
+    fetch_tile(kbeg);
     store_tile();
     __syncthreads();
     for (int it = 0; it < ntiles; it++) {
-        const int t0 = 32 * it;
+        const int t0 = kbeg + 32 * it;
         if (it + 1 < ntiles)
             fetch_tile(t0 + 32);
         if (my_nq > 0 && t0 <= wave_last) { // wave-uniform
@@ -834,7 +844,7 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
                 sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf[4 * s4 + 3], sacc, 0, 0, 0);
             }
             // keys after the query's own position are not attended to (model_chunked.hpp:186)
-            if (t0 + 31 > item.pos0 + wq0) {
+            if (t0 + 31 > item.pos0 + wq0 || t0 + 31 > kmax) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int key = t0 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -880,6 +890,22 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
     if (!q_live)
         return;
     l += __shfl_xor(l, 32); // q_live is the same for lane and lane^32
+    if (item.nparts > 1) {
+        // split-K: the unnormalised partial of this key range; rows whose queries precede it carry (m, l, o) = (-big, 0, 0)
+        const int64_t rec = (((int64_t)(item.row0 + wq0 + j) * p.max_parts + item.part) * p.n_heads + head);
+        if (half == 0)
+            *reinterpret_cast<float2 *>(p.ws_ml + rec * 2) = make_float2(m, l);
+#pragma unroll
+        for (int c = 0; c < HDP / 32; c++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int dim = 32 * c + 8 * g + 4 * half;
+                if (dim < hd)
+                    *reinterpret_cast<float4 *>(p.ws_o + rec * hd + dim) =
+                        make_float4(o[c][4 * g], o[c][4 * g + 1], o[c][4 * g + 2], o[c][4 * g + 3]);
+            }
+        return;
+    }
     const float mf  = fmaxf(m, kRefMaxFloorLog2); // the reference's max_val = -1e10 floor (model_chunked.hpp:197)
     const float f   = fast_exp2(m - mf);
     const float inv = f / (l * f);

@@ -412,7 +412,7 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
 
     if (sh.max_chunks > 1) {
         const int  vecs = n_heads * (pool->head_dim / 4);
-        const dim3 mgrid((unsigned)((vecs + 255) / 256), (unsigned)plan->num_seqs);
+        const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)((vecs + 255) / 256));
         hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
                            plan->counters + 1, out_dev, n_heads, pool->head_dim, sh.max_chunks);
         HIP_TRY(hipGetLastError());
@@ -532,39 +532,78 @@ int stage_chunk_rows(nvk_pool *pool, int num_seqs, const int *starts, const int 
 
 constexpr int kPrefillMaxTableEntries = 4096; // table slice a tiled-prefill workgroup stages in LDS (16 KiB)
 
-// TILED prefill: one work item per (sequence, tile of 32*qsubs query tokens), longest key range first.
-// Built on the host from the chunk list and uploaded on `st`.  *n_items = 0 when nothing is to be done.
-int stage_prefill_items(nvk_pool *pool, int num_seqs, const int *starts, const int *lens, int max_blocks, int qsubs,
-                        hipStream_t st, const nvk::PrefillItem **items_dev, int *n_items, int *max_ctx)
+// TILED prefill: work items = (sequence, tile of 32*qsubs query tokens) x key-range parts, longest first.
+// Built on the host from the chunk list and uploaded on `st`.  When the call has fewer (tile, head-group)
+// pairs than about twice the chip's workgroup slots, every tile's key range is cut into parts of `kc` keys
+// (split-K) and *row_parts_dev gets, per packed query row, the number of parts to merge (1 = none).
+struct PrefillWork
 {
-    std::vector<nvk::PrefillItem> items;
-    const int                     tile = 32 * qsubs;
-    int                           row = 0, top = 0;
+    const nvk::PrefillItem *items_dev = nullptr;
+    const int              *row_parts_dev = nullptr;
+    int                     n_items = 0, max_ctx = 0, max_parts = 1, total_q = 0;
+};
+
+int stage_prefill_items(nvk_pool *pool, int num_seqs, const int *starts, const int *lens, int max_blocks, int qsubs,
+                        int grid_y, hipStream_t st, PrefillWork *work)
+{
+    const int tile = 32 * qsubs;
+    long long tiles = 0, key_work = 0; // key_work: keys scanned, summed over tiles
+    int       top = 0, total_q = 0;
     for (int s = 0; s < num_seqs; s++) {
         if (starts[s] < 0 || lens[s] < 0 || (long long)starts[s] + lens[s] > (long long)max_blocks * pool->block_size)
             return nvk::fail(NVK_ERR_INVALID_ARG, "prefill: chunk %d (start %d, length %d) does not fit its table row", s,
                              starts[s], lens[s]);
-        for (int q0 = 0; q0 < lens[s]; q0 += tile)
-            items.push_back(nvk::PrefillItem{s, row + q0, starts[s] + q0, std::min(tile, lens[s] - q0)});
-        row += lens[s];
+        for (int q0 = 0; q0 < lens[s]; q0 += tile) {
+            tiles++;
+            key_work += starts[s] + std::min(q0 + tile, lens[s]);
+        }
+        total_q += lens[s];
         if (lens[s] > 0)
             top = std::max(top, starts[s] + lens[s]);
     }
-    *n_items = (int)items.size();
-    *max_ctx = top;
-    if (items.empty())
+    work->total_q = total_q, work->max_ctx = top, work->n_items = 0, work->max_parts = 1;
+    if (tiles == 0)
         return NVK_OK;
+    // two 4-wave workgroups fit a CU; aim at about two rounds of them before cutting key ranges
+    const long long slots = 2LL * pool->num_cus;
+    int             kc    = 0x7fffffff;
+    if (tiles * grid_y < 2 * slots) {
+        const long long want = (key_work * grid_y + 2 * slots - 1) / (2 * slots);
+        kc                   = (int)std::max<long long>(256, (want + 31) / 32 * 32);
+    }
+    std::vector<nvk::PrefillItem> items;
+    std::vector<int>              row_parts((size_t)total_q, 1);
+    int                           row = 0;
+    for (int s = 0; s < num_seqs; s++) {
+        for (int q0 = 0; q0 < lens[s]; q0 += tile) {
+            const int nq = std::min(tile, lens[s] - q0), keys = starts[s] + q0 + nq;
+            const int np = (int)(((long long)keys + kc - 1) / kc);
+            for (int part = 0; part < np; part++)
+                items.push_back(nvk::PrefillItem{s, row + q0, starts[s] + q0, nq, part * kc,
+                                                 (int)std::min<long long>((long long)(part + 1) * kc, keys), part, np});
+            if (np > 1)
+                std::fill(row_parts.begin() + row + q0, row_parts.begin() + row + q0 + nq, np);
+            work->max_parts = std::max(work->max_parts, np);
+        }
+        row += lens[s];
+    }
     std::stable_sort(items.begin(), items.end(), [](const nvk::PrefillItem &a, const nvk::PrefillItem &b) {
-        return a.pos0 + a.nq > b.pos0 + b.nq; // the longest key ranges start first
+        return std::min(a.k1, a.pos0 + a.nq) - a.k0 > std::min(b.k1, b.pos0 + b.nq) - b.k0; // longest key ranges first
     });
-    int rc = ensure_desc(pool, items.size() * 4);
+    work->n_items = (int)items.size();
+    const size_t item_ints = items.size() * (sizeof(nvk::PrefillItem) / sizeof(int));
+    const size_t rows_ints = work->max_parts > 1 ? (size_t)total_q : 0;
+    int rc = ensure_desc(pool, item_ints + rows_ints);
     if (rc != NVK_OK)
         return rc;
-    std::memcpy(pool->desc_host, items.data(), items.size() * sizeof(nvk::PrefillItem));
-    HIP_TRY(hipMemcpyAsync(pool->desc_dev, pool->desc_host, items.size() * sizeof(nvk::PrefillItem),
-                           hipMemcpyHostToDevice, st));
+    std::memcpy(pool->desc_host, items.data(), item_ints * sizeof(int));
+    if (rows_ints)
+        std::memcpy(pool->desc_host + item_ints, row_parts.data(), rows_ints * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(pool->desc_dev, pool->desc_host, (item_ints + rows_ints) * sizeof(int), hipMemcpyHostToDevice,
+                           st));
     HIP_TRY(hipEventRecord(pool->desc_ev, st));
-    *items_dev = reinterpret_cast<const nvk::PrefillItem *>(pool->desc_dev);
+    work->items_dev     = reinterpret_cast<const nvk::PrefillItem *>(pool->desc_dev);
+    work->row_parts_dev = rows_ints ? pool->desc_dev + item_ints : nullptr;
     return NVK_OK;
 }
 
@@ -1463,28 +1502,41 @@ int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, con
     if (flags == NVK_PREFILL_TILED || (flags == NVK_PREFILL_AUTO && tiled_ok && max_chunk >= 8)) {
         const int kv_mul = n_heads / pool->n_kv_heads;
         const int hpw    = kv_mul % 4 == 0 ? 4 : (kv_mul % 2 == 0 ? 2 : 1);
-        const nvk::PrefillItem *items = nullptr;
-        int                     n_items = 0, max_ctx = 0;
-        rc = stage_prefill_items(pool, num_seqs, chunk_starts, chunk_lens, max_blocks, 4 / hpw, st, &items, &n_items,
-                                 &max_ctx);
-        if (rc != NVK_OK || n_items == 0)
+        const int    grid_y = pool->n_kv_heads * (kv_mul / hpw);
+        PrefillWork  work;
+        rc = stage_prefill_items(pool, num_seqs, chunk_starts, chunk_lens, max_blocks, 4 / hpw, grid_y, st, &work);
+        if (rc != NVK_OK || work.n_items == 0)
             return rc;
+        if (work.max_parts > 1) {
+            rc = ensure_workspace(pool, (size_t)work.total_q * work.max_parts * n_heads * pool->head_dim,
+                                  (size_t)work.total_q * work.max_parts * n_heads * 2);
+            if (rc != NVK_OK)
+                return rc;
+        }
         nvk::PrefillParams pp;
         pp.k_layer = pool->k_layer(layer), pp.v_layer = pool->v_layer(layer), pp.q = q_dev;
-        pp.block_tables = block_tables_dev, pp.items = items, pp.out = out_dev;
+        pp.block_tables = block_tables_dev, pp.items = work.items_dev, pp.out = out_dev;
+        pp.ws_o = pool->ws_o, pp.ws_ml = pool->ws_ml, pp.max_parts = work.max_parts;
         pp.max_blocks = max_blocks, pp.num_blocks = pool->num_blocks, pp.block_size = pool->block_size;
         pp.bs_magic = pool->bs_magic, pp.n_kv_heads = pool->n_kv_heads, pp.n_heads = n_heads, pp.kv_mul = kv_mul;
         pp.head_dim = pool->head_dim, pp.hpw = hpw;
         pp.q_scale  = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
         const int    hdp  = pool->head_dim <= 64 ? 64 : 128;
-        const int    nblk = (max_ctx + pool->block_size - 1) / pool->block_size;
+        const int    nblk = (work.max_ctx + pool->block_size - 1) / pool->block_size;
         const size_t lds  = ((size_t)32 * (hdp + 4) + (size_t)32 * (hdp + 8)) * sizeof(float) + (size_t)(nblk + 1) * sizeof(int);
-        const dim3   grid((unsigned)n_items, (unsigned)(pool->n_kv_heads * (kv_mul / hpw)));
+        const dim3   grid((unsigned)work.n_items, (unsigned)grid_y);
         if (hdp == 64)
             hipLaunchKernelGGL((nvk::nvk_prefill_kernel<64>), grid, dim3(256), lds, st, pp);
         else
             hipLaunchKernelGGL((nvk::nvk_prefill_kernel<128>), grid, dim3(256), lds, st, pp);
         HIP_TRY(hipGetLastError());
+        if (work.max_parts > 1) { // combine the key-range partials per query row (rows with one part are done)
+            const int  vecs = n_heads * (pool->head_dim / 4);
+            const dim3 mgrid((unsigned)work.total_q, (unsigned)((vecs + 255) / 256));
+            hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, st, pool->ws_o, pool->ws_ml, work.row_parts_dev,
+                               out_dev, n_heads, pool->head_dim, work.max_parts);
+            HIP_TRY(hipGetLastError());
+        }
         return NVK_OK;
     }
 

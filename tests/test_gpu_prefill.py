@@ -134,3 +134,20 @@ def test_random_geometry_prefill_against_checker(seed):
         for flags in MODES:
             got = nv.prefill(pool, 0, q, work.block_tables, starts, lens, flags)
             assert_close(got, want, f"H{H} KV{KV} hd{hd} bs{bs} starts{starts.tolist()} lens{lens.tolist()} flags={flags}")
+
+
+def test_long_context_small_batch_splits_keys():
+    """One sequence deep into a long prompt: too few tiles to fill the chip, so key ranges are split over
+    workgroups and merged (split-K prefill); checked against the checker and the row-wise form."""
+    g = wl.Geometry(8, 2, 128, 16)
+    for start, n in ((3000, 100), (0, 700), (5000, 1)):
+        work = wl.fragmented_workload("prefill_long", np.array([start + n], np.int32), g)
+        k_host, v_host, tabs, _ = wl.host_blocks_for(work, [0])
+        q = wl.uniform(55, 0, n * g.n_heads * g.head_dim).reshape(n, g.n_heads, g.head_dim)
+        want = ol.oracle_paged_prefill(q, k_host, v_host, tabs[0], start, g.block_size, g.n_kv_heads)
+        with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+            pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+            tiled = nv.prefill(pool, 0, q, work.block_tables, [start], [n], nv.PREFILL_TILED)
+            assert_close(tiled, want, f"tiled start={start} n={n}")
+            rowwise = nv.prefill(pool, 0, q, work.block_tables, [start], [n], nv.PREFILL_ROWWISE)
+            assert_close(rowwise, want, f"rowwise start={start} n={n}")
