@@ -106,6 +106,11 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
                                const float *v_rows, const int *block_tables, int max_blocks, const int *positions,
                                float rope_theta, int ptr_kind, void *stream);
 
+/* Prebuilds the frequency table for `rope_theta` (a pool is created with the table for 10000, the
+ * reference's default).  The RoPE entry points rebuild it themselves when they meet another theta, which
+ * synchronises the device and is not allowed under stream capture: call this first in that case. */
+int nvk_pool_set_rope_theta(nvk_pool *pool, float rope_theta);
+
 /* The same for CHUNKS of new tokens: sequence s brings chunk_lens[s] tokens at
  * positions chunk_starts[s] + b; rows of q / k_rows / v_rows are packed back to back in sequence order
  * (sum of chunk_lens rows in all).  chunk_starts / chunk_lens are always HOST arrays; ptr_kind says

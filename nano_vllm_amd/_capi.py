@@ -71,6 +71,7 @@ SIGNATURES = {
     "nvk_pool_append_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "nvk_pool_rope_append_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp,
                                              C.c_float, C.c_int, _vp]),
+    "nvk_pool_set_rope_theta": (C.c_int, [_vp, C.c_float]),
     "nvk_pool_rope_append_chunks": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp,
                                               C.c_float, C.c_int, _vp]),
     "nvk_prefill": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int]),

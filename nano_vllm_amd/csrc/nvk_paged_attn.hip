@@ -163,6 +163,26 @@ int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
     return NVK_OK;
 }
 
+// inv_freq[p] = 1 / powf(theta, 2p / head_dim): the reference's own expression (ops/positional.hpp:16,
+// batch_ops.hpp:34) through the host libm, rebuilt only when theta changes.  The device buffer exists from
+// pool creation (theta 10000, the reference's config.rope_theta), so the RoPE entry points neither allocate
+// nor copy synchronously on their hot path -- they can run under stream capture.
+int ensure_rope_table(nvk_pool *pool, float rope_theta)
+{
+    if (pool->rope_inv_freq && pool->rope_theta == rope_theta)
+        return NVK_OK;
+    const int          hd = pool->head_dim, half = hd / 2;
+    std::vector<float> freq((size_t)std::max(half, 1));
+    for (int i = 0; i + 1 < hd; i += 2)
+        freq[(size_t)(i / 2)] = 1.0f / powf(rope_theta, (float)i / hd);
+    if (!pool->rope_inv_freq)
+        HIP_TRY(hipMalloc(&pool->rope_inv_freq, freq.size() * sizeof(float)));
+    HIP_TRY(hipDeviceSynchronize()); // an earlier launch on another stream may still read the old table
+    HIP_TRY(hipMemcpy(pool->rope_inv_freq, freq.data(), freq.size() * sizeof(float), hipMemcpyHostToDevice));
+    pool->rope_theta = rope_theta;
+    return NVK_OK;
+}
+
 int check_pool_layer(const nvk_pool *pool, int layer, const char *who)
 {
     if (!pool)
@@ -816,8 +836,23 @@ int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads
         nvk_pool_destroy(pool);
         return code;
     }
+    if (head_dim % 2 == 0) {
+        const int rc = ensure_rope_table(pool, 10000.0f); // config.rope_theta, include/core/model.hpp:40
+        if (rc != NVK_OK) {
+            nvk_pool_destroy(pool);
+            return rc;
+        }
+    }
     *out_pool = pool;
     return NVK_OK;
+}
+
+int nvk_pool_set_rope_theta(nvk_pool *pool, float rope_theta)
+{
+    if (!pool || !(rope_theta > 0.f) || pool->head_dim % 2 != 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_set_rope_theta: bad arguments");
+    DeviceScope scope(pool->device);
+    return ensure_rope_table(pool, rope_theta);
 }
 
 int nvk_pool_destroy(nvk_pool *pool)
@@ -996,17 +1031,10 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
     const int   hd   = pool->head_dim;
     const int   half = hd / 2;
 
-    // inv_freq[p] = 1 / powf(theta, 2p / head_dim): the reference's own expression (positional.hpp:16)
-    // through the host libm, rebuilt only when theta changes
-    if (rotate && (!pool->rope_inv_freq || pool->rope_theta != rope_theta)) {
-        std::vector<float> freq((size_t)half);
-        for (int i = 0; i < hd; i += 2)
-            freq[(size_t)(i / 2)] = 1.0f / powf(rope_theta, (float)i / hd);
-        if (!pool->rope_inv_freq)
-            HIP_TRY(hipMalloc(&pool->rope_inv_freq, (size_t)half * sizeof(float)));
-        HIP_TRY(hipDeviceSynchronize()); // an earlier launch on another stream may still read the old table
-        HIP_TRY(hipMemcpy(pool->rope_inv_freq, freq.data(), (size_t)half * sizeof(float), hipMemcpyHostToDevice));
-        pool->rope_theta = rope_theta;
+    if (rotate) {
+        rc = ensure_rope_table(pool, rope_theta);
+        if (rc != NVK_OK)
+            return rc;
     }
 
     const int    row = pool->row_len();
@@ -1419,15 +1447,10 @@ int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_h
     if (rc != NVK_OK || rows.total_q == 0)
         return rc;
     const int hd = pool->head_dim, half = hd / 2, row = pool->row_len();
-    if (rotate && (!pool->rope_inv_freq || pool->rope_theta != rope_theta)) {
-        std::vector<float> freq((size_t)half);
-        for (int i = 0; i < hd; i += 2)
-            freq[(size_t)(i / 2)] = 1.0f / powf(rope_theta, (float)i / hd); // positional.hpp:16 / batch_ops.hpp:34
-        if (!pool->rope_inv_freq)
-            HIP_TRY(hipMalloc(&pool->rope_inv_freq, (size_t)half * sizeof(float)));
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(pool->rope_inv_freq, freq.data(), (size_t)half * sizeof(float), hipMemcpyHostToDevice));
-        pool->rope_theta = rope_theta;
+    if (rotate) {
+        rc = ensure_rope_table(pool, rope_theta);
+        if (rc != NVK_OK)
+            return rc;
     }
     float       *dq = q;
     const float *dk = k_rows, *dv = v_rows;

@@ -146,6 +146,10 @@ class PagedKVPool:
                                                          float(rope_theta), _capi.PTR_HOST, None))
         return qh
 
+    def set_rope_theta(self, rope_theta: float) -> None:
+        """Prebuild the RoPE frequency table for another theta (needed before capturing a stream)."""
+        _capi.check(_capi.lib.nvk_pool_set_rope_theta(self.handle, float(rope_theta)))
+
     def rope_append_batch_device(self, layer: int, num_seqs: int, n_heads: int, q_dev, k_rows_dev, v_rows_dev,
                                  block_tables_dev, max_blocks: int, positions_dev, rope_theta: float = 10000.0,
                                  stream=None) -> None:

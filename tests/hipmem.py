@@ -39,3 +39,49 @@ class DeviceArray:
             self.ptr = C.c_void_p()
 
     __del__ = free
+
+
+# ---- streams and graphs (tests of capture-safety of the device-pointer entry points) ----
+_hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+_hip.hipStreamDestroy.argtypes = [C.c_void_p]
+_hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+_hip.hipStreamBeginCapture.argtypes = [C.c_void_p, C.c_int]
+_hip.hipStreamEndCapture.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+_hip.hipGraphInstantiate.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+_hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+_hip.hipGraphExecDestroy.argtypes = [C.c_void_p]
+_hip.hipGraphDestroy.argtypes = [C.c_void_p]
+
+
+class Stream:
+    def __init__(self):
+        self.h = C.c_void_p()
+        assert _hip.hipStreamCreate(C.byref(self.h)) == 0
+
+    def data_ptr(self) -> int:
+        return int(self.h.value)
+
+    def synchronize(self):
+        assert _hip.hipStreamSynchronize(self.h) == 0
+
+    def capture(self, fn):
+        """Runs fn() under stream capture and returns an instantiated graph (hipGraphExec_t)."""
+        assert _hip.hipStreamBeginCapture(self.h, 0) == 0  # hipStreamCaptureModeGlobal
+        try:
+            fn()
+        finally:
+            graph = C.c_void_p()
+            rc = _hip.hipStreamEndCapture(self.h, C.byref(graph))
+        assert rc == 0, f"hipStreamEndCapture -> {rc}"
+        exe = C.c_void_p()
+        assert _hip.hipGraphInstantiate(C.byref(exe), graph, None, None, 0) == 0
+        _hip.hipGraphDestroy(graph)
+        return exe
+
+    def launch(self, exe):
+        assert _hip.hipGraphLaunch(exe, self.h) == 0
+
+    def close(self):
+        if self.h:
+            _hip.hipStreamDestroy(self.h)
+            self.h = C.c_void_p()

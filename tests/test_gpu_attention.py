@@ -474,3 +474,59 @@ def test_random_geometry_batches_against_checker(seed):
         for flags, ch in ((nv.AUTO, 0), (nv.SINGLE_PASS, 0), (nv.SPLIT_K, chunk)):
             got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, flags, ch)
             assert_close(got, want, f"H{H} KV{KV} hd{hd} bs{bs} ctx{ctx.tolist()} flags={flags} chunk={ch}")
+
+
+def test_planned_decode_is_capturable_in_a_hip_graph():
+    """The per-layer entry point allocates nothing and synchronises nothing, so the layer loop of a model step
+    can be captured once and replayed: plan build + L x (rope+append, attention) as one hipGraph."""
+    from hipmem import DeviceArray, Stream, _hip
+
+    g = wl.Geometry(8, 2, 64, 16)
+    L = 3
+    ctx = np.array([300, 17, 1000, 64, 129], np.int32)
+    work = wl.fragmented_workload("graph", ctx + 1, g)  # room for the token the step appends
+    n = work.num_seqs
+    rng = np.random.default_rng(8)
+    q = rng.standard_normal((n, g.n_heads, g.head_dim), dtype=np.float32)
+    k = rng.standard_normal((n, g.row_len), dtype=np.float32)
+    v = rng.standard_normal((n, g.row_len), dtype=np.float32)
+
+    def run(use_graph):
+        with nv.PagedKVPool(L, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+            for layer in range(L):
+                pool.fill_uniform(layer, 10 + layer, 20 + layer)
+            st = Stream()
+            qd = [DeviceArray(q) for _ in range(L)]  # rope rotates q in place: one buffer per layer
+            kd, vd = DeviceArray(k), DeviceArray(v)
+            tabs, pos, lens = DeviceArray(work.block_tables), DeviceArray(ctx), DeviceArray(ctx + 1)
+            outs = [DeviceArray(np.full_like(q, np.nan)) for _ in range(L)]
+            plan = nv.DecodePlan(pool)
+            pool.reserve_workspace(n, g.n_heads, work.max_ctx)
+            plan.build(n, g.n_heads, lens, work.max_ctx, stream=st)  # sizes the plan: the captured rebuild allocates nothing
+            st.synchronize()
+
+            def step():
+                plan.build(n, g.n_heads, lens, work.max_ctx, stream=st)
+                for layer in range(L):
+                    pool.rope_append_batch_device(layer, n, g.n_heads, qd[layer], kd, vd, tabs, work.max_blocks, pos,
+                                                  stream=st)
+                    plan.run(layer, qd[layer], tabs, work.max_blocks, outs[layer], stream=st)
+
+            if use_graph:
+                exe = st.capture(step)
+                assert all(np.isnan(o.numpy()).all() for o in outs)  # capture records, it does not run
+                st.launch(exe)
+                st.synchronize()
+                _hip.hipGraphExecDestroy(exe)
+            else:
+                step()
+                st.synchronize()
+            res = [o.numpy() for o in outs]
+            plan.close()
+            st.close()
+            return res
+
+    eager, graphed = run(False), run(True)
+    for layer in range(L):
+        assert np.isfinite(eager[layer]).all()
+        assert np.array_equal(eager[layer].view(np.uint32), graphed[layer].view(np.uint32)), layer
