@@ -23,6 +23,9 @@ ap.add_argument("--ctx", type=int, default=2048)
 ap.add_argument("--layers", type=int, default=4, help="layers held in the pool (a step runs --model-layers layer calls over them)")
 ap.add_argument("--model-layers", type=int, default=32)
 ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--graph", action="store_true",
+                help="capture the step's layer loop in a hipGraph once and replay it (measurement of the device-side "
+                     "time without host launch cost; lengths do not advance between replays)")
 args = ap.parse_args()
 
 g = wl.G_LLAMA
@@ -57,14 +60,34 @@ with nv.PagedKVPool(args.layers, nb, bs, g.n_kv_heads, g.head_dim) as pool, \
     warm = time.perf_counter() - t0
     model_step(args.model_layers)  # warm-up (sizes the split-K workspace)
     pool.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model_step(args.model_layers)
-    pool.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    if args.graph:
+        from hipmem import Stream
+        stream = Stream()
+        batch.begin_step(ids, g.n_heads, stream=stream)
+        stream.synchronize()
+
+        def layers():
+            for i in range(args.model_layers):
+                batch.layer(i % args.layers, q, k, v, out, 10000.0, stream=stream)
+
+        exe = stream.capture(layers)
+        stream.launch(exe)
+        stream.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stream.launch(exe)
+        stream.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        batch.end_step()
+    else:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model_step(args.model_layers)
+        pool.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
     st = batch.stats()
 ctx_mid = args.ctx + 1 + (args.steps + 1) / 2
 kv_bytes = args.model_layers * args.seqs * (2 * ctx_mid * g.row_len * 4 + 2 * g.n_heads * g.head_dim * 4 + 3 * g.row_len * 4)
-print(f"decode batch: {args.seqs} requests x ctx {args.ctx}, {args.model_layers} layer calls per step: "
+print(f"decode batch{' (hipGraph replay)' if args.graph else ''}: {args.seqs} requests x ctx {args.ctx}, {args.model_layers} layer calls per step: "
       f"{dt * 1e3:8.3f} ms/step  {args.seqs / dt:10.0f} tokens/s  attention path {kv_bytes / dt / 1e9:7.1f} GB/s "
       f"({100 * kv_bytes / dt / 8e12:4.1f}% of HBM peak)  bookkeeping-only steps {warm / args.ctx * 1e6:6.1f} us each  {st}")
