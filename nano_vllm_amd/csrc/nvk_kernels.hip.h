@@ -867,11 +867,20 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
             }
             m = mn;
             l = fmaf(l, alpha, psum); // this lane half's share of the row sum; joined at the end
+#ifndef NVK_PREFILL_ALWAYS_RESCALE
+            // the running max settles after the first tiles of a row: skip the HDP/2 multiplies per lane
+            // whenever no query of the wave saw a new maximum (alpha == 1 everywhere)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0)
+#endif
+            {
+#pragma unroll
+                for (int c = 0; c < HDP / 32; c++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        o[c][r] *= alpha;
+            }
 #pragma unroll
             for (int c = 0; c < HDP / 32; c++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    o[c][r] *= alpha;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int   key = (r & 3) + 8 * (r >> 2) + 4 * half; // the key register r of this half holds
