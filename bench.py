@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--replan", type=int, default=1,
                     help="rebuild the decode plan every N layer-calls inside the timed region "
                          "(1 = every call; 32 = as for the 32 layers of one model step)")
+    ap.add_argument("--strong", action="store_true",
+                    help="sequence-sharded strong scaling: ONE batch of the workload's shape is split over the ranks "
+                         "by context tokens (sharding.partition_sequences) instead of one batch per rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1: nccl (= RCCL, the real one) or gloo (rehearsal of the "
                          "multi-process path on a box with fewer GPUs than ranks; ranks then share GPUs)")
@@ -214,8 +217,19 @@ def main():
             dist.init_process_group("gloo")
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the timing reduction lives
 
-    work = make_workload(args.workload, rank, args.geom)
+    work = make_workload(args.workload, 0 if args.strong else rank, args.geom)
     g = work.geom
+    whole_bytes = None
+    if args.strong and args.shard == "seq" and world > 1:
+        # this rank's share of the one batch: its own pool and tables (block ids are rank-local), nothing exchanged
+        from nano_vllm_amd import sharding as sh
+        from nano_vllm_amd import workloads as wl
+
+        whole_bytes = work.algorithmic_bytes()
+        mine = sh.partition_sequences(work.ctx_lens, world)[rank]
+        work = wl.fragmented_workload(work.name + f"_part{rank}of{world}", work.ctx_lens[mine], g) if work.fragmented \
+            else wl.Workload(work.name + f"_part{rank}of{world}", g, work.num_blocks, work.ctx_lens[mine],
+                             work.block_tables[mine], False)
     flags = {"auto": nv.AUTO, "single": nv.SINGLE_PASS, "split": nv.SPLIT_K}[args.mode]
 
     def barrier():
@@ -298,9 +312,12 @@ def main():
     if rank == 0:
         nbytes = work.algorithmic_bytes()  # per rank, per layer-call
         ms_per_step = wall * 1e3 / args.steps
-        value = nbytes * world / (ms_per_step * 1e-3) / 1e9
+        job_bytes = whole_bytes if whole_bytes is not None else nbytes * world
+        value = job_bytes / (ms_per_step * 1e-3) / 1e9
         achieved = nbytes / (attn_ms * 1e-3) / 1e9
         seqs_all = work.num_seqs * (world if args.shard == "seq" else 1)  # head shards all hold the same batch
+        if whole_bytes is not None:
+            seqs_all = make_workload(args.workload, 0, args.geom).num_seqs
         line = {
             "metric": "paged_attn_decode_achieved_hbm_GBps",
             "value": round(value, 1),
@@ -310,7 +327,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak" if args.shard == "seq" else "strong",
+            "scaling": "weak" if (args.shard == "seq" and not args.strong) else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
