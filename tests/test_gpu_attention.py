@@ -530,3 +530,69 @@ def test_planned_decode_is_capturable_in_a_hip_graph():
     for layer in range(L):
         assert np.isfinite(eager[layer]).all()
         assert np.array_equal(eager[layer].view(np.uint32), graphed[layer].view(np.uint32)), layer
+
+
+def test_pool_beyond_int32_offsets():
+    """The reference computes pool offsets in int (attention.hpp:114-115, model.hpp:196-198) and is only defined
+    below 2^31 floats per slab; the device pool is addressed in 64 bits.  Two layers of 9.2 GB each per K and V,
+    sequences placed in blocks whose float offsets exceed 2^31 and, in layer 1, 2^32."""
+    g = wl.G_LLAMA
+    nb = 140_000  # 140000 * 16 * 1024 floats = 2.29e9 floats per slab > 2^31
+    top = [139_999, 131_073, 135_000, 131_072, 139_000, 132_000, 137_777, 138_888]
+    ctx = np.array([50, 64], np.int32)
+    tabs = np.array([top[:4], top[4:]], np.int32)
+    assert int(tabs.min()) * g.block_floats >= 2 ** 31  # every block used lies beyond what an int offset reaches
+    q = wl.uniform(3, 0, 2 * g.n_heads * g.head_dim).reshape(2, g.n_heads, g.head_dim)
+    with nv.PagedKVPool(2, nb, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(1, 5, 6)
+        work = wl.Workload("big", g, nb, ctx, tabs)
+        k_host = np.stack([wl.uniform_block(5, int(pb), g.block_floats).reshape(g.block_size, g.n_kv_heads, g.head_dim)
+                           for pb in tabs.reshape(-1)])
+        v_host = np.stack([wl.uniform_block(6, int(pb), g.block_floats).reshape(g.block_size, g.n_kv_heads, g.head_dim)
+                           for pb in tabs.reshape(-1)])
+        local = np.arange(8, dtype=np.int32).reshape(2, 4)
+        want = ol.oracle_decode_batch(q, k_host, v_host, local, ctx, g.block_size, g.n_kv_heads)
+        for flags, chunk in ((nv.AUTO, 0), (nv.SPLIT_K, 16)):
+            got = nv.decode(pool, 1, q, work.block_tables, ctx, flags, chunk)
+            assert_close(got, want, f"flags={flags}")
+        kb, _ = pool.download_block(1, 139_999)
+        assert np.array_equal(kb.reshape(-1), wl.uniform_block(5, 139_999, g.block_floats))
+        k0, _ = pool.download_block(0, 139_999)
+        assert not k0.any()  # layer 0 untouched: the layer offset is 64-bit too
+        # an appended row lands where the 64-bit arithmetic says
+        krow = np.full(g.row_len, 7.0, np.float32)
+        pool.append(1, 139_999, 15, krow, -krow)
+        kb, vb = pool.download_block(1, 139_999)
+        assert np.array_equal(kb[15].reshape(-1), krow) and np.array_equal(vb[15].reshape(-1), -krow)
+
+
+def test_two_pools_driven_from_two_host_threads():
+    """Distinct pools may be driven concurrently from different host threads (include/nvk_paged_attn.h, threading)."""
+    import threading
+
+    g = wl.Geometry(8, 2, 64, 16)
+    ctx = np.array([300, 17, 1000, 64, 129, 0, 511], np.int32)
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            work = wl.fragmented_workload(f"thread{tid}", ctx + tid, g, perm_seed=50 + tid)
+            q = work.q()
+            k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(work.num_seqs)))
+            with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+                pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+                for _ in range(20):
+                    got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, nv.SPLIT_K, 64)
+            want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, g.block_size, g.n_kv_heads)
+            results[tid] = (got, want)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tid, (got, want) in results.items():
+        assert_close(got, want, f"thread {tid}")
