@@ -748,13 +748,18 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
     float *s_v   = s_mem + 32 * KS;
     int   *s_tab = reinterpret_cast<int *>(s_v + 32 * VS);
 
-    const PrefillItem item = p.items[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, half = lane >> 5;
+    // 1-D grid, head group fastest: workgroups launched together are the head groups of ONE item, walking the
+    // same token rows at the same time, so whole [n_kv_heads * head_dim] rows are consumed together (DRAM pages,
+    // Infinity Cache) instead of one 512-B piece of many rows
     const int hpw    = p.hpw;
     const int groups = p.kv_mul / hpw;
-    const int kvh    = blockIdx.y / groups;
-    const int head   = kvh * p.kv_mul + (blockIdx.y % groups) * hpw + wave % hpw;
+    const int grid_y = p.n_kv_heads * groups;
+    const int by     = blockIdx.x % grid_y;
+    const PrefillItem item = p.items[blockIdx.x / grid_y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int kvh    = by / groups;
+    const int head   = kvh * p.kv_mul + (by % groups) * hpw + wave % hpw;
     const int wq0    = 32 * (wave / hpw);            // first query of this wave inside the item
     const int my_nq  = min(32, item.nq - wq0);       // <= 0: the wave only helps with the loads
     const bool q_live = j < my_nq;

@@ -1547,7 +1547,10 @@ int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, con
         const int    hdp  = pool->head_dim <= 64 ? 64 : 128;
         const int    nblk = (work.max_ctx + pool->block_size - 1) / pool->block_size;
         const size_t lds  = ((size_t)32 * (hdp + 4) + (size_t)32 * (hdp + 8)) * sizeof(float) + (size_t)(nblk + 1) * sizeof(int);
-        const dim3   grid((unsigned)work.n_items, (unsigned)grid_y);
+        if ((long long)work.n_items * grid_y > 0x7fffffffLL)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_prefill_device: %d tiles x %d head groups exceed the grid",
+                             work.n_items, grid_y);
+        const dim3   grid((unsigned)(work.n_items * grid_y));
         if (hdp == 64)
             hipLaunchKernelGGL((nvk::nvk_prefill_kernel<64>), grid, dim3(256), lds, st, pp);
         else
