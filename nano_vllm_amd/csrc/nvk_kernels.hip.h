@@ -101,6 +101,7 @@ struct DecodeParams
     int             kv_waves;  // kv-heads (= waves along the kv axis) per workgroup; the workgroup's other
                                // blockDim/64/kv_waves waves split the chunk's tokens among themselves
     int             merge_off; // int offset of the token-split merge area behind the table slice in LDS
+    int             items_padded; // item slots per (kv-head group, q sub-group): the item bound, a multiple of 8 when qsplit > 1
     float           q_scale;   // log2(e) / sqrt(head_dim)
 };
 
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(kPlanThreads)
 // VPL   float4 per lane per row (head_dim <= 64*VPL)
 // QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.y also walks kv_mul/QPK)
 // FULL  head_dim == 64*VPL, so no lane is idle and no load needs a predicate
-// grid: x = work item (upper bound; workgroups past *n_items leave), y = kv-head group x q sub-group
+// grid: 1-D over (work item, kv-head group x q sub-group); workgroups past *n_items leave
 // Waves: wave w owns kv-head (w % kv_waves) of the group; when the pool has fewer than 8 kv-heads
 // (a head-sharded rank, small models; fewer than 4 for 256-float rows) the remaining waves split the
 // chunk's tokens ("token-split"):
@@ -284,9 +285,22 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     constexpr int kStepTokens = step_tokens(VPL);  // tokens per wave per pipeline step
     extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice (+ merge area)
 
-    if ((int)blockIdx.x >= *p.n_items)
+    // 1-D grid: kv-head group outermost, then (item, q sub-group).  The q sub-groups of an item (only when a GQA
+    // group has more q-heads than one wave carries) read the very same K/V bytes: ids are dealt in blocks of
+    // 8 * qsplit so that id and id + 8 are the same item, and -- workgroup ids going round-robin over the 8 XCDs --
+    // they run on one XCD at about the same time and meet in its L2.
+    const int qsplit = p.kv_mul / QPK;
+    const int inner  = p.items_padded * qsplit; // workgroups per kv-head group
+    const int kvg    = blockIdx.x / inner;
+    int       item_i = blockIdx.x - kvg * inner, zq = 0;
+    if (qsplit > 1) {
+        const int span = 8 * qsplit, rem = item_i % span;
+        item_i         = item_i / span * 8 + rem % 8;
+        zq             = rem / 8;
+    }
+    if (item_i >= *p.n_items)
         return;
-    const WorkItem item  = p.items[blockIdx.x];
+    const WorkItem item  = p.items[item_i];
     const int      seq   = item.seq;
     const int      chunk = item.w & 0xFFFF;
     const int      nch   = item.w >> 16; // chunks of this sequence: 1 -> this workgroup writes `out` itself
@@ -300,11 +314,9 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     const int r      = lane & 15; // which 16 B of a 256-B row piece
 
     // blockIdx.y enumerates (kv-head group, q sub-group); waves enumerate kv-heads in the group
-    const int  qsplit = p.kv_mul / QPK;
-    const int  zq     = blockIdx.y % qsplit;
     const int  parts  = nwaves / p.kv_waves; // token-split factor (1 when the group has 8 kv-heads)
     const int  part   = wave / p.kv_waves;
-    const int  kvh    = (blockIdx.y / qsplit) * p.kv_waves + wave % p.kv_waves;
+    const int  kvh    = kvg * p.kv_waves + wave % p.kv_waves;
     const bool live   = kvh < p.n_kv_heads;
     const int  qh0    = kvh * p.kv_mul + zq * QPK; // first q-head of this wave
 

@@ -22,6 +22,9 @@
 #ifndef NVK_WG_WAVES
 #define NVK_WG_WAVES 8 // kv-heads (= waves) per workgroup, at most
 #endif
+#ifndef NVK_MAX_QPK
+#define NVK_MAX_QPK 8 // q-heads one wave carries at most (register budget: q and the accumulators grow with it)
+#endif
 #ifndef NVK_AUTO_MAX_CHUNK
 #define NVK_AUTO_MAX_CHUNK 2048 // longest chunk NVK_DECODE_AUTO picks
 #endif
@@ -221,7 +224,16 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     const int kv_mul = n_heads / pool->n_kv_heads;
     plan->vpl        = hd <= 64 ? 1 : (hd <= 128 ? 2 : 4);
     plan->full       = hd == 64 * plan->vpl;
-    plan->qpk        = kv_mul % 4 == 0 ? 4 : (kv_mul % 2 == 0 ? 2 : 1);
+    // q-heads per wave: the whole GQA group when it has at most 8 heads (K/V then cross HBM and L2 once),
+    // else its largest divisor up to 8 (the q sub-groups of an item re-read K/V; the grid pairs them on one XCD)
+    // (measured register budget: 8 q-heads fit beside two tiles for rows of <= 64 floats, 6 for longer rows;
+    // 7 or 8 there spill a hundred registers)
+    plan->qpk = 1;
+    for (int d = std::min(kv_mul, plan->vpl == 1 ? NVK_MAX_QPK : std::min(NVK_MAX_QPK, 6)); d >= 1; d--)
+        if (kv_mul % d == 0) {
+            plan->qpk = d;
+            break;
+        }
     const int wg_waves = std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl));
     plan->waves      = std::min(pool->n_kv_heads, wg_waves);
     plan->kv_groups  = (pool->n_kv_heads + plan->waves - 1) / plan->waves;
@@ -281,8 +293,17 @@ template <int VPL, int QPK> hipError_t launch_decode_full(bool full, dim3 grid, 
 template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
                                                 const nvk::DecodeParams &p)
 {
+    if constexpr (VPL == 1) {
+        if (qpk == 8)
+            return launch_decode_full<VPL, 8>(full, grid, block, lds, stream, p);
+        if (qpk == 7)
+            return launch_decode_full<VPL, 7>(full, grid, block, lds, stream, p);
+    }
     switch (qpk) {
+    case 6: return launch_decode_full<VPL, 6>(full, grid, block, lds, stream, p);
+    case 5: return launch_decode_full<VPL, 5>(full, grid, block, lds, stream, p);
     case 4: return launch_decode_full<VPL, 4>(full, grid, block, lds, stream, p);
+    case 3: return launch_decode_full<VPL, 3>(full, grid, block, lds, stream, p);
     case 2: return launch_decode_full<VPL, 2>(full, grid, block, lds, stream, p);
     default: return launch_decode_full<VPL, 1>(full, grid, block, lds, stream, p);
     }
@@ -422,7 +443,13 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     p.merge_off    = sh.merge_off;
     p.q_scale      = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
 
-    const dim3 grid((unsigned)plan->item_bound, (unsigned)(sh.kv_groups * (kv_mul / sh.qpk)));
+    const int       qsplit = kv_mul / sh.qpk;
+    const int       padded = qsplit > 1 ? round_up(plan->item_bound, 8) : plan->item_bound;
+    const long long wgs    = (long long)padded * qsplit * sh.kv_groups;
+    if (wgs > 0x7fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "decode: %lld workgroups exceed the grid", wgs);
+    p.items_padded = padded;
+    const dim3 grid((unsigned)wgs);
     const dim3 block((unsigned)(sh.waves * sh.parts) * 64);
     if (ev_attn_begin)
         HIP_TRY(hipEventRecord(ev_attn_begin, stream));
