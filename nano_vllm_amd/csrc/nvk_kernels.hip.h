@@ -56,8 +56,10 @@ static_assert(NVK_STEP_TOKENS % 4 == 0 && NVK_STEP_TOKENS >= 4, "a step is whole
 #ifndef NVK_TPL_VPL1
 #define NVK_TPL_VPL1 4 // tokens per lane per step for rows of <= 64 floats (twice the others: same bytes in flight)
 #endif
-constexpr int tok_per_lane(int vpl) { return vpl == 1 ? NVK_TPL_VPL1 : NVK_STEP_TOKENS / 4; }
-constexpr int step_tokens(int vpl) { return 4 * tok_per_lane(vpl); }
+// (7 or 8 q-heads over rows of more than 64 floats: q and the accumulators take 128 registers, so the tiles
+// shrink to one token per lane -- half the bytes in flight, but K/V are read once instead of twice)
+constexpr int tok_per_lane(int vpl, int qpk) { return vpl == 1 ? NVK_TPL_VPL1 : (qpk > 6 ? 1 : NVK_STEP_TOKENS / 4); }
+constexpr int step_tokens(int vpl, int qpk) { return 4 * tok_per_lane(vpl, qpk); }
 // Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) for rows of up to 128 floats; 4 (one per SIMD,
 // the whole register file) for 256-float rows, whose q, accumulators and two tiles for all four q-heads
 // of a group need about 300 registers -- cheaper than reading K/V once per q-head pair.
@@ -151,10 +153,10 @@ __device__ __forceinline__ float dot4(const float4 &a, const float4 &b, float ac
     return acc;
 }
 
-template <int VPL> struct KVTile
+template <int VPL, int TPL> struct KVTile
 {
-    float4 k[tok_per_lane(VPL)][VPL];
-    float4 v[tok_per_lane(VPL)][VPL];
+    float4 k[TPL][VPL];
+    float4 v[TPL][VPL];
 };
 
 __device__ __forceinline__ float4 load_kv(const float *p)
@@ -281,8 +283,9 @@ __global__ void __launch_bounds__(kPlanThreads)
 template <int VPL, int QPK, bool FULL>
 __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(const DecodeParams p)
 {
-    constexpr int kTokPerLane = tok_per_lane(VPL); // tokens each lane holds per step
-    constexpr int kStepTokens = step_tokens(VPL);  // tokens per wave per pipeline step
+    constexpr int kTokPerLane = tok_per_lane(VPL, QPK); // tokens each lane holds per step
+    constexpr int kStepTokens = step_tokens(VPL, QPK);  // tokens per wave per pipeline step
+    using Tile                = KVTile<VPL, kTokPerLane>;
     extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice (+ merge area)
 
     // 1-D grid: kv-head group outermost, then (item, q sub-group).  The q sub-groups of an item (only when a GQA
@@ -396,7 +399,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     const int lane_col = kvh * hd + 4 * r; // float offset of this lane inside a token row
     const int row_len  = p.n_kv_heads * hd;
 
-    auto load_tile = [&](KVTile<VPL> &T, int ts) {
+    auto load_tile = [&](Tile &T, int ts) {
         int64_t at[kTokPerLane];
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++) {
@@ -426,7 +429,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     };
 
     // TAIL = false: every token of the step is inside the chunk, no masking needed
-    auto consume_tile = [&](const KVTile<VPL> &T, int ts, auto tail) {
+    auto consume_tile = [&](const Tile &T, int ts, auto tail) {
         constexpr bool TAIL = decltype(tail)::value;
         float          s[kTokPerLane][QPK];
 #pragma unroll
@@ -483,7 +486,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     const std::integral_constant<bool, true>  tail;
     if (has_tokens) {
         const int   nsteps = (w1 - w0 + kStepTokens - 1) / kStepTokens;
-        KVTile<VPL> ta, tb;
+        Tile        ta, tb;
         int         k = 0;
         load_tile(ta, w0);
         for (; k + 2 < nsteps; k += 2) {

@@ -226,10 +226,9 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     plan->full       = hd == 64 * plan->vpl;
     // q-heads per wave: the whole GQA group when it has at most 8 heads (K/V then cross HBM and L2 once),
     // else its largest divisor up to 8 (the q sub-groups of an item re-read K/V; the grid pairs them on one XCD)
-    // (measured register budget: 8 q-heads fit beside two tiles for rows of <= 64 floats, 6 for longer rows;
-    // 7 or 8 there spill a hundred registers)
+    // (register budget: 256-float rows stop at 6 q-heads; 128-float rows take 7 or 8 with one-token tiles)
     plan->qpk = 1;
-    for (int d = std::min(kv_mul, plan->vpl == 1 ? NVK_MAX_QPK : std::min(NVK_MAX_QPK, 6)); d >= 1; d--)
+    for (int d = std::min(kv_mul, plan->vpl == 4 ? std::min(NVK_MAX_QPK, 6) : NVK_MAX_QPK); d >= 1; d--)
         if (kv_mul % d == 0) {
             plan->qpk = d;
             break;
@@ -241,7 +240,7 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     // the chunk's tokens, so the workgroup still has all its waves' loads in flight
     plan->parts      = plan->kv_groups == 1 ? std::max(1, wg_waves / plan->waves) : 1;
 
-    const int step    = nvk::step_tokens(plan->vpl);
+    const int step    = nvk::step_tokens(plan->vpl, plan->qpk);
     const int ctx_cap = round_up(std::max(max_ctx, 1), step);
     // a workgroup stages its chunk's table slice in LDS: bound the chunk by that
     const long long slice_cap = (long long)kMaxTableSliceEntries * pool->block_size / step * step;
@@ -293,7 +292,7 @@ template <int VPL, int QPK> hipError_t launch_decode_full(bool full, dim3 grid, 
 template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
                                                 const nvk::DecodeParams &p)
 {
-    if constexpr (VPL == 1) {
+    if constexpr (VPL <= 2) {
         if (qpk == 8)
             return launch_decode_full<VPL, 8>(full, grid, block, lds, stream, p);
         if (qpk == 7)
