@@ -450,13 +450,13 @@ def test_rope_append_then_decode_like_a_batched_model_step():
                 assert_close(got[s], want, f"step {t} seq {s}")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(36))
 def test_random_geometry_batches_against_checker(seed):
     """Differential sweep: random head geometry (every VPL / QPK / token-split / kv-group combination), block size,
     ragged lengths and fragmented tables, each in auto, single-pass and a random split-K chunking."""
     d = wl.splitmix64(4200 + seed, np.arange(12, dtype=np.uint64)).tolist()
     KV = [1, 2, 3, 4, 5, 6, 8, 12, 16][d[0] % 9]
-    H = KV * [1, 2, 3, 4, 8][d[1] % 5]
+    H = KV * [1, 2, 3, 4, 5, 6, 7, 8, 16][(d[1] + seed) % 9]  # every q-heads-per-wave count, and two q sub-groups
     hd = [4, 16, 20, 48, 64, 80, 96, 128, 132, 192, 256][d[2] % 11]
     bs = [1, 4, 8, 12, 16, 32][d[3] % 6]
     n = 1 + d[4] % 9
