@@ -288,6 +288,16 @@ int nvk_batch_num_requests(const nvk_batch *batch);
 int nvk_batch_request_len(const nvk_batch *batch, int request_id);                       /* tokens in the pool */
 int nvk_batch_request_blocks(const nvk_batch *batch, int request_id, int *ids, int cap); /* count; = block_ids */
 int nvk_batch_begin_step(nvk_batch *batch, const int *request_ids, int n, int n_heads, void *stream);
+/* A step that also brings CHUNKS (chunked prefill beside decode, what ScheduledBatch's two lists describe,
+ * include/scheduler/scheduler.hpp:24-43): request i takes chunk_lens[i] >= 1 tokens.  List the one-token
+ * (decode) requests first; rows of q / k_rows / v_rows / out for nvk_batch_layer are then one per decode
+ * request followed by the chunks' rows packed in list order (nvk_batch_step_rows in all).  Per layer the
+ * decode part runs as above and the chunks run RoPE + append of all their tokens, then chunked-prefill
+ * attention (experimental/chunked_prefill/model_chunked.hpp:79-96).  With every chunk_lens[i] == 1 this is
+ * nvk_batch_begin_step. */
+int nvk_batch_begin_step_chunks(nvk_batch *batch, const int *request_ids, const int *chunk_lens, int n, int n_heads,
+                                void *stream);
+int nvk_batch_step_rows(const nvk_batch *batch);
 int nvk_batch_layer(nvk_batch *batch, int layer, float *q_dev, const float *k_rows_dev, const float *v_rows_dev,
                     float *out_dev, float rope_theta, void *stream);
 int nvk_batch_end_step(nvk_batch *batch);

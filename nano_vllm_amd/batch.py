@@ -54,6 +54,16 @@ class DecodeBatch:
         ids = (C.c_int * max(len(request_ids), 1))(*[int(r) for r in request_ids])
         _capi.check(_capi.lib.nvk_batch_begin_step(self._h, ids, len(request_ids), int(n_heads), _devptr(stream)))
 
+    def begin_step_chunks(self, request_ids: Sequence[int], chunk_lens: Sequence[int], n_heads: int,
+                          stream=None) -> int:
+        """A step where request i takes ``chunk_lens[i]`` tokens (decode requests, one token each, listed first;
+        prefill chunks behind them).  Returns the number of q/k/v/out rows the step's layer calls expect."""
+        n = len(request_ids)
+        ids = (C.c_int * max(n, 1))(*[int(r) for r in request_ids])
+        lens = (C.c_int * max(n, 1))(*[int(c) for c in chunk_lens])
+        _capi.check(_capi.lib.nvk_batch_begin_step_chunks(self._h, ids, lens, n, int(n_heads), _devptr(stream)))
+        return _capi.check(_capi.lib.nvk_batch_step_rows(self._h))
+
     def layer(self, layer: int, q_dev, k_rows_dev, v_rows_dev, out_dev, rope_theta: float = 10000.0,
               stream=None) -> None:
         _capi.check(_capi.lib.nvk_batch_layer(self._h, int(layer), _devptr(q_dev), _devptr(k_rows_dev),

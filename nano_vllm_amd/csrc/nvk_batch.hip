@@ -85,9 +85,16 @@ struct nvk_batch
     std::vector<Slot>            slots; // dense; a finished request's slot is taken by the last one
     std::unordered_map<int, int> slot_of;
 
+    int row_len = 0, head_dim = 0; // floats per K/V token row, per head
+
     // the step in flight
     bool             in_step = false;
     int              n_heads = 0;
+    // a step that brings chunks (prefill) as well: the first n_decode requests take one token each, the rest
+    // take step_chunks[i] tokens at positions step_starts[i].. (host copies, what the prefill entry points want)
+    bool             chunked  = false;
+    int              n_decode = 0;
+    std::vector<int> step_chunks, step_starts;
     std::vector<int> step_ids, resident_ids; // resident_ids: the list whose tables/positions are in HBM now
     bool             resident_valid = false;
 
@@ -158,6 +165,7 @@ int nvk_batch_create(nvk_pool *pool, nvk_block_manager *bm, int max_seqs, int ma
         return nvk::fail(NVK_ERR_OOM, "nvk_batch_create: host allocation failed");
     b->pool = pool, b->bm = bm, b->max_seqs = max_seqs, b->max_blocks = max_blocks_per_seq;
     b->block_size = geo[2], b->device = geo[5];
+    b->row_len = geo[3] * geo[4], b->head_dim = geo[4];
     DeviceScope  scope(b->device);
     const size_t tab = (size_t)max_seqs * max_blocks_per_seq * sizeof(int);
     const size_t vec = (size_t)max_seqs * sizeof(int);
@@ -382,8 +390,133 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
         return rc;
     }
     b->n_heads = n_heads;
+    b->chunked = false;
     b->in_step = true;
     return NVK_OK;
+}
+
+int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int *chunk_lens, int n, int n_heads,
+                                void *stream)
+{
+    if (!b || n < 0 || (n > 0 && (!request_ids || !chunk_lens)) || n_heads <= 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step_chunks: bad arguments");
+    bool all_one = true;
+    for (int i = 0; i < n; i++) {
+        if (chunk_lens[i] < 1)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step_chunks: request %d brings %d tokens",
+                             request_ids[i], chunk_lens[i]);
+        all_one = all_one && chunk_lens[i] == 1;
+    }
+    if (all_one)
+        return nvk_batch_begin_step(b, request_ids, n, n_heads, stream); // a pure decode step: the resident-table path
+    if (b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step_chunks: the previous step was not ended");
+    if (n > b->max_seqs)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step_chunks: %d requests, %d slots", n, b->max_seqs);
+
+    // 1. validate; blocks needed so that every request holds ceil((len + chunk) / block_size) of them
+    std::vector<int> slot_idx((size_t)n), fresh((size_t)n);
+    long long        need = 0;
+    {
+        std::unordered_map<int, int> seen;
+        for (int i = 0; i < n; i++) {
+            auto it = b->slot_of.find(request_ids[i]);
+            if (it == b->slot_of.end())
+                return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step_chunks: request %d is not running",
+                                 request_ids[i]);
+            if (!seen.emplace(request_ids[i], i).second)
+                return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step_chunks: request %d listed twice",
+                                 request_ids[i]);
+            slot_idx[(size_t)i] = it->second;
+            const Slot     &s    = b->slots[(size_t)it->second];
+            const long long want = ((long long)s.len + chunk_lens[i] + b->block_size - 1) / b->block_size;
+            if (want > b->max_blocks)
+                return nvk::fail(NVK_ERR_INVALID_ARG,
+                                 "nvk_batch_begin_step_chunks: request %d would reach %lld tokens, its table holds %d blocks",
+                                 s.request_id, (long long)s.len + chunk_lens[i], b->max_blocks);
+            fresh[(size_t)i] = (int)(want - (long long)s.blocks.size());
+            need += fresh[(size_t)i];
+        }
+    }
+    if (need > nvk_bm_num_free_blocks(b->bm))
+        return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks (%lld needed, %d free)", need,
+                         nvk_bm_num_free_blocks(b->bm));
+
+    DeviceScope scope(b->device);
+    hipStream_t st = stream_or_pool(b, stream);
+    HIP_TRY(hipEventSynchronize(b->staged));
+
+    // 2. allocate in list order (block_manager.hpp:145-154, as many times as the chunk needs)
+    for (int i = 0; i < n; i++) {
+        Slot &s = b->slots[(size_t)slot_idx[(size_t)i]];
+        for (int k = 0; k < fresh[(size_t)i]; k++) {
+            const int id = nvk_bm_allocate_block_for_request(b->bm, s.request_id);
+            if (id < 0) { // raced with another thread: give this step's blocks back
+                for (int u = 0; u <= i; u++) {
+                    Slot &t = b->slots[(size_t)slot_idx[(size_t)u]];
+                    for (int r = (u == i ? k : fresh[(size_t)u]); r > 0; r--) {
+                        nvk_bm_free_block_safe(b->bm, t.blocks.back());
+                        t.blocks.pop_back();
+                    }
+                }
+                b->resident_valid = false;
+                return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks");
+            }
+            s.blocks.push_back(id);
+        }
+    }
+
+    // 3. the step's rows: the leading one-token requests are the decode part (ScheduledBatch::decode_requests),
+    //    everything behind them the prefill part (ScheduledBatch::prefill_requests)
+    int nd = 0;
+    while (nd < n && chunk_lens[nd] == 1)
+        nd++;
+    b->step_chunks.assign(chunk_lens, chunk_lens + n);
+    b->step_starts.resize((size_t)n);
+    int max_ctx = 0;
+    for (int i = 0; i < n; i++) {
+        const Slot &s   = b->slots[(size_t)slot_idx[(size_t)i]];
+        int        *row = b->h_tables + (size_t)i * b->max_blocks;
+        std::copy(s.blocks.begin(), s.blocks.end(), row);
+        std::fill(row + s.blocks.size(), row + b->max_blocks, 0);
+        b->step_starts[(size_t)i] = s.len;
+        if (i < nd) {
+            b->h_pos[i] = s.len;
+            b->h_ctx[i] = s.len + 1;
+            max_ctx     = std::max(max_ctx, s.len + 1);
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(b->d_tables, b->h_tables, (size_t)n * b->max_blocks * sizeof(int), hipMemcpyHostToDevice, st));
+    if (nd > 0) {
+        HIP_TRY(hipMemcpyAsync(b->d_pos, b->h_pos, (size_t)nd * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_ctx, b->h_ctx, (size_t)nd * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipEventRecord(b->staged, st));
+    b->full_uploads++;
+    b->step_ids.assign(request_ids, request_ids + n);
+    b->resident_valid = false; // the next pure decode step re-sends its tables once
+    if (nd > 0) {
+        int rc = nvk_plan_build(b->plan, nd, n_heads, b->d_ctx, max_ctx, NVK_DECODE_AUTO, 0, (void *)st);
+        if (rc != NVK_OK)
+            return rc;
+    }
+    b->n_heads  = n_heads;
+    b->chunked  = true;
+    b->n_decode = nd;
+    b->in_step  = true;
+    return NVK_OK;
+}
+
+int nvk_batch_step_rows(const nvk_batch *b)
+{
+    if (!b || !b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_step_rows: no step in flight");
+    if (!b->chunked)
+        return (int)b->step_ids.size();
+    long long rows = 0;
+    for (int c : b->step_chunks)
+        rows += c;
+    return (int)rows;
 }
 
 int nvk_batch_layer(nvk_batch *b, int layer, float *q_dev, const float *k_rows_dev, const float *v_rows_dev,
@@ -398,6 +531,35 @@ int nvk_batch_layer(nvk_batch *b, int layer, float *q_dev, const float *k_rows_d
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_layer: bad arguments");
     DeviceScope scope(b->device);
     hipStream_t st = stream_or_pool(b, stream);
+    if (b->chunked) {
+        // decode part: rows [0, nd), one per request; prefill part: the chunks' rows packed behind them
+        const int    nd = b->n_decode, np = n - nd;
+        const size_t qrow = (size_t)b->n_heads * b->head_dim;
+        if (nd > 0) {
+            int rc = nvk_pool_rope_append_batch(b->pool, layer, nd, b->n_heads, q_dev, k_rows_dev, v_rows_dev, b->d_tables,
+                                                b->max_blocks, b->d_pos, rope_theta, NVK_PTR_DEVICE, (void *)st);
+            if (rc == NVK_OK)
+                rc = nvk_decode_planned(b->pool, layer, b->plan, q_dev, b->d_tables, b->max_blocks, out_dev, (void *)st);
+            if (rc != NVK_OK)
+                return rc;
+        }
+        if (np > 0) {
+            float       *q2 = q_dev + (size_t)nd * qrow;
+            const float *k2 = k_rows_dev + (size_t)nd * b->row_len, *v2 = v_rows_dev + (size_t)nd * b->row_len;
+            const int   *t2 = b->d_tables + (size_t)nd * b->max_blocks;
+            // forward_chunk's order (model_chunked.hpp:79-96): rope + append the whole chunk, then chunked attention
+            int rc = nvk_pool_rope_append_chunks(b->pool, layer, np, b->n_heads, q2, k2, v2, t2, b->max_blocks,
+                                                 b->step_starts.data() + nd, b->step_chunks.data() + nd, rope_theta,
+                                                 NVK_PTR_DEVICE, (void *)st);
+            if (rc == NVK_OK)
+                rc = nvk_prefill_device(b->pool, layer, np, b->n_heads, q2, t2, b->max_blocks, b->step_starts.data() + nd,
+                                        b->step_chunks.data() + nd, out_dev + (size_t)nd * qrow, NVK_PREFILL_AUTO,
+                                        (void *)st);
+            if (rc != NVK_OK)
+                return rc;
+        }
+        return NVK_OK;
+    }
     // KV append for every sequence of the step (model.hpp:190-207), with the rotation of model.hpp:169-175 when asked
     int rc = nvk_pool_rope_append_batch(b->pool, layer, n, b->n_heads, q_dev, k_rows_dev, v_rows_dev, b->d_tables,
                                         b->max_blocks, b->d_pos, rope_theta, NVK_PTR_DEVICE, (void *)st);
@@ -411,9 +573,10 @@ int nvk_batch_end_step(nvk_batch *b)
 {
     if (!b || !b->in_step)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_end_step: no step in flight");
-    for (int id : b->step_ids)
-        b->slots[(size_t)b->slot_of[id]].len += 1;
+    for (size_t i = 0; i < b->step_ids.size(); i++)
+        b->slots[(size_t)b->slot_of[b->step_ids[i]]].len += b->chunked ? b->step_chunks[i] : 1;
     b->in_step = false;
+    b->chunked = false;
     return NVK_OK;
 }
 

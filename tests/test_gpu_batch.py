@@ -142,3 +142,71 @@ def test_plain_append_mode_matches_append_batch():
                 want = ol.oracle_paged_attention(q[i], hk, hv, table, t + 1, bs, hd, H, KV)
                 assert close(got[i], want), (t, rid)
             batch.end_step()
+
+
+def test_chunked_prefill_beside_decode_in_one_batch():
+    """ScheduledBatch's two lists in one step (scheduler.hpp:24-43): running requests decode one token while newly
+    admitted ones feed their prompts in chunks of at most 24 tokens; per layer rope + append + attention for all.
+    Every output row is checked against the checker's rope -> append -> paged_attention for that token."""
+    L, H, KV, hd, bs = 2, 8, 2, 64, 8
+    nb, max_seqs, max_blocks, chunk_cap = 96, 6, 12, 24
+    theta = 10000.0
+    rng = np.random.default_rng(33)
+    # request id -> (step it joins, prompt tokens, tokens to generate after the prompt)
+    plan = {1: (0, 50, 12), 2: (0, 7, 20), 3: (2, 61, 5), 4: (4, 24, 9), 5: (9, 1, 6)}
+    host_k = np.zeros((L, nb, bs, KV, hd), np.float32)
+    host_v = np.zeros_like(host_k)
+    fed, running = {}, []
+    bm = nv.BlockManager(nb, bs)
+    steps_with_both = 0
+    with nv.PagedKVPool(L, nb, bs, KV, hd) as pool, nv.DecodeBatch(pool, bm, max_seqs, max_blocks) as batch:
+        step = 0
+        while step < 80 and (running or any(j >= step for j, _, _ in plan.values())):
+            for rid, (join, _, _) in plan.items():
+                if join == step:
+                    batch.add_request(rid)
+                    running.append(rid)
+                    fed[rid] = 0
+            decode_ids = [r for r in running if fed[r] >= plan[r][1]]
+            prefill_ids = [r for r in running if fed[r] < plan[r][1]]
+            ids = decode_ids + prefill_ids  # decode requests first
+            chunks = [1] * len(decode_ids) + [min(chunk_cap, plan[r][1] - fed[r]) for r in prefill_ids]
+            if ids:
+                steps_with_both += bool(decode_ids) and any(c > 1 for c in chunks)
+                rows = batch.begin_step_chunks(ids, chunks, H)
+                assert rows == sum(chunks)
+                for layer in range(L):
+                    q = rng.standard_normal((rows, H, hd), dtype=np.float32)
+                    k = rng.standard_normal((rows, KV, hd), dtype=np.float32)
+                    v = rng.standard_normal((rows, KV, hd), dtype=np.float32)
+                    qd, kd, vd = DeviceArray(q), DeviceArray(k), DeviceArray(v)
+                    outd = DeviceArray(np.full_like(q, np.nan))
+                    batch.layer(layer, qd, kd, vd, outd, theta)
+                    pool.synchronize()
+                    got = outd.numpy()
+                    r0 = 0
+                    for rid, c in zip(ids, chunks):
+                        table = np.asarray(batch.request_blocks(rid), np.int32)
+                        for b in range(c):  # append the whole chunk first (forward_chunk's order), then attend
+                            pos = fed[rid] + b
+                            _, wk = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q[r0 + b], k[r0 + b], pos, hd, H, KV, theta)
+                            host_k[layer, table[pos // bs], pos % bs] = wk
+                            host_v[layer, table[pos // bs], pos % bs] = v[r0 + b]
+                        for b in range(c):
+                            pos = fed[rid] + b
+                            wq, _ = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q[r0 + b], k[r0 + b], pos, hd, H, KV, theta)
+                            want = ol.oracle_paged_attention(wq, host_k[layer], host_v[layer], table, pos + 1, bs, hd, H, KV)
+                            assert close(got[r0 + b], want), (step, layer, rid, b, float(np.abs(got[r0 + b] - want).max()))
+                        r0 += c
+                batch.end_step()
+                for rid, c in zip(ids, chunks):
+                    fed[rid] += c
+                    assert batch.request_len(rid) == fed[rid]
+                    assert len(batch.request_blocks(rid)) == (fed[rid] + bs - 1) // bs
+            for rid in list(running):
+                if fed[rid] >= plan[rid][1] + plan[rid][2]:
+                    batch.finish_request(rid)
+                    running.remove(rid)
+            step += 1
+        assert not running and bm.get_num_free_blocks() == nb
+        assert steps_with_both >= 3  # the schedule really mixes decode rows and prefill chunks in one step
