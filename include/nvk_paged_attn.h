@@ -11,6 +11,10 @@
  *
  * Threading: a pool is thread-compatible (external synchronisation per pool);
  * distinct pools (one per GPU) may be driven from different host threads.
+ * Streams: the split-K partials of decode and prefill calls on one pool live
+ * in ONE workspace owned by the pool, so launches on a pool must be ordered
+ * with respect to each other (one stream, or events between streams); pools
+ * are independent of each other.
  * nvk_bm_* is safe exactly where the reference's BlockManager is: the
  * *_for_request / *_safe entry points lock, the plain ones do not.
  */

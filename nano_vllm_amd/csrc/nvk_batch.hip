@@ -308,7 +308,8 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
                 return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step: request %d listed twice", request_ids[i]);
             slot_idx[(size_t)i] = it->second;
             const Slot &s       = b->slots[(size_t)it->second];
-            if (s.len % b->block_size == 0) {
+            // held blocks do not cover token `len` (a step that failed after allocating keeps its blocks: no second draw)
+            if ((long long)s.blocks.size() * b->block_size <= s.len) {
                 if (s.len / b->block_size >= b->max_blocks)
                     return nvk::fail(NVK_ERR_INVALID_ARG,
                                      "nvk_batch_begin_step: request %d is at %d tokens, its table holds %d blocks",
@@ -328,10 +329,11 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
     // 2. allocate, in list order, through the per-request API (block_manager.hpp:145-154)
     const bool same_list = b->resident_valid && (int)b->resident_ids.size() == n
                            && std::equal(request_ids, request_ids + n, b->resident_ids.begin());
+    b->resident_valid = false; // until this step's tables are known to be on their way
     int n_patches = 0, max_ctx = 0;
     for (int i = 0; i < n; i++) {
         Slot &s = b->slots[(size_t)slot_idx[(size_t)i]];
-        if (s.len % b->block_size == 0) {
+        if ((long long)s.blocks.size() * b->block_size <= s.len) {
             const int id = nvk_bm_allocate_block_for_request(b->bm, s.request_id);
             if (id < 0) { // another thread took blocks between the check and here: undo this step's allocations
                 for (int k = 0; k < n_patches; k++) {
@@ -339,7 +341,6 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
                     nvk_bm_free_block_safe(b->bm, u.blocks.back());
                     u.blocks.pop_back();
                 }
-                b->resident_valid = false;
                 return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks");
             }
             b->h_patches[3 * n_patches]     = i;
@@ -380,15 +381,13 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
         HIP_TRY(hipEventRecord(b->staged, st));
     }
     b->step_ids.assign(request_ids, request_ids + n);
-    b->resident_ids   = b->step_ids;
-    b->resident_valid = n > 0;
+    b->resident_ids = b->step_ids;
 
     // 4. one plan for all the layers of this step
     int rc = nvk_plan_build(b->plan, n, n_heads, b->d_ctx, max_ctx, NVK_DECODE_AUTO, 0, (void *)st);
-    if (rc != NVK_OK) {
-        b->resident_valid = false;
-        return rc;
-    }
+    if (rc != NVK_OK)
+        return rc; // positions in HBM may have moved on without the step: resident_valid stays false
+    b->resident_valid = n > 0;
     b->n_heads = n_heads;
     b->chunked = false;
     b->in_step = true;
@@ -416,7 +415,11 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
 
     // 1. validate; blocks needed so that every request holds ceil((len + chunk) / block_size) of them
     std::vector<int> slot_idx((size_t)n), fresh((size_t)n);
-    long long        need = 0;
+    long long        need = 0, rows = 0;
+    for (int i = 0; i < n; i++)
+        rows += chunk_lens[i];
+    if (rows > 0x7fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_begin_step_chunks: %lld rows in one step", rows);
     {
         std::unordered_map<int, int> seen;
         for (int i = 0; i < n; i++) {
@@ -434,7 +437,7 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
                 return nvk::fail(NVK_ERR_INVALID_ARG,
                                  "nvk_batch_begin_step_chunks: request %d would reach %lld tokens, its table holds %d blocks",
                                  s.request_id, (long long)s.len + chunk_lens[i], b->max_blocks);
-            fresh[(size_t)i] = (int)(want - (long long)s.blocks.size());
+            fresh[(size_t)i] = (int)std::max(0LL, want - (long long)s.blocks.size());
             need += fresh[(size_t)i];
         }
     }
@@ -445,6 +448,7 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
     DeviceScope scope(b->device);
     hipStream_t st = stream_or_pool(b, stream);
     HIP_TRY(hipEventSynchronize(b->staged));
+    b->resident_valid = false; // rows of a mixed step are not the decode list: the next decode step re-sends its tables
 
     // 2. allocate in list order (block_manager.hpp:145-154, as many times as the chunk needs)
     for (int i = 0; i < n; i++) {
@@ -459,7 +463,6 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
                         t.blocks.pop_back();
                     }
                 }
-                b->resident_valid = false;
                 return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks");
             }
             s.blocks.push_back(id);
@@ -494,7 +497,6 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
     HIP_TRY(hipEventRecord(b->staged, st));
     b->full_uploads++;
     b->step_ids.assign(request_ids, request_ids + n);
-    b->resident_valid = false; // the next pure decode step re-sends its tables once
     if (nd > 0) {
         int rc = nvk_plan_build(b->plan, nd, n_heads, b->d_ctx, max_ctx, NVK_DECODE_AUTO, 0, (void *)st);
         if (rc != NVK_OK)

@@ -23,6 +23,10 @@ ap.add_argument("--ctx", type=int, default=2048)
 ap.add_argument("--layers", type=int, default=4, help="layers held in the pool (a step runs --model-layers layer calls over them)")
 ap.add_argument("--model-layers", type=int, default=32)
 ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--prefill-chunk", type=int, default=0,
+                help="mixed steps: one more request feeds a prompt chunk of this many tokens in every step "
+                     "(nvk_batch_begin_step_chunks), beside the --seqs decoding requests")
+ap.add_argument("--prefill-ctx", type=int, default=0, help="tokens that request already holds when timing starts")
 ap.add_argument("--graph", action="store_true",
                 help="capture the step's layer loop in a hipGraph once and replay it (measurement of the device-side "
                      "time without host launch cost; lengths do not advance between replays)")
@@ -30,23 +34,35 @@ args = ap.parse_args()
 
 g = wl.G_LLAMA
 bs = g.block_size
-max_blocks = (args.ctx + args.steps + bs - 1) // bs + 1
-nb = args.seqs * max_blocks
+dec_blocks = (args.ctx + args.steps + bs - 1) // bs + 1
+pre_blocks = (args.prefill_ctx + args.prefill_chunk * (args.steps + 2) + bs - 1) // bs + 1 if args.prefill_chunk else 0
+max_blocks = max(dec_blocks, pre_blocks)
+nb = args.seqs * dec_blocks + pre_blocks
+rows = args.seqs + args.prefill_chunk
 bm = nv.BlockManager(nb, bs)
 with nv.PagedKVPool(args.layers, nb, bs, g.n_kv_heads, g.head_dim) as pool, \
-        nv.DecodeBatch(pool, bm, args.seqs, max_blocks) as batch:
+        nv.DecodeBatch(pool, bm, args.seqs + 1, max_blocks) as batch:
     for layer in range(args.layers):
         pool.fill_uniform(layer, 1 + layer, 100 + layer)
     ids = list(range(args.seqs))
     for r in ids:
         batch.add_request(r)
-    q = DeviceArray(wl.uniform(3, 0, args.seqs * g.n_heads * g.head_dim).reshape(args.seqs, g.n_heads, g.head_dim))
-    k = DeviceArray(wl.uniform(4, 0, args.seqs * g.row_len).reshape(args.seqs, g.row_len))
-    v = DeviceArray(wl.uniform(5, 0, args.seqs * g.row_len).reshape(args.seqs, g.row_len))
-    out = DeviceArray(np.zeros((args.seqs, g.n_heads, g.head_dim), np.float32))
+    q = DeviceArray(wl.uniform(3, 0, rows * g.n_heads * g.head_dim).reshape(rows, g.n_heads, g.head_dim))
+    k = DeviceArray(wl.uniform(4, 0, rows * g.row_len).reshape(rows, g.row_len))
+    v = DeviceArray(wl.uniform(5, 0, rows * g.row_len).reshape(rows, g.row_len))
+    out = DeviceArray(np.zeros((rows, g.n_heads, g.head_dim), np.float32))
+    PREFILL_ID = args.seqs
+    if args.prefill_chunk:
+        batch.add_request(PREFILL_ID)
+        if args.prefill_ctx:  # bookkeeping only, like the decode requests below
+            batch.begin_step_chunks([PREFILL_ID], [args.prefill_ctx], g.n_heads)
+            batch.end_step()
 
     def model_step(layer_calls):
-        batch.begin_step(ids, g.n_heads)
+        if args.prefill_chunk:
+            batch.begin_step_chunks(ids + [PREFILL_ID], [1] * args.seqs + [args.prefill_chunk], g.n_heads)
+        else:
+            batch.begin_step(ids, g.n_heads)
         for i in range(layer_calls):
             batch.layer(i % args.layers, q, k, v, out, 10000.0)
         batch.end_step()
@@ -61,6 +77,7 @@ with nv.PagedKVPool(args.layers, nb, bs, g.n_kv_heads, g.head_dim) as pool, \
     model_step(args.model_layers)  # warm-up (sizes the split-K workspace)
     pool.synchronize()
     if args.graph:
+        assert not args.prefill_chunk, "--graph times pure decode steps"
         from hipmem import Stream
         stream = Stream()
         batch.begin_step(ids, g.n_heads, stream=stream)
@@ -87,6 +104,11 @@ with nv.PagedKVPool(args.layers, nb, bs, g.n_kv_heads, g.head_dim) as pool, \
         dt = (time.perf_counter() - t0) / args.steps
     st = batch.stats()
 ctx_mid = args.ctx + 1 + (args.steps + 1) / 2
+if args.prefill_chunk:
+    pos_mid = args.prefill_ctx + args.prefill_chunk * (1 + args.steps / 2)  # start of the middle timed step's chunk
+    flops = args.model_layers * 4 * g.n_heads * g.head_dim * args.prefill_chunk * (pos_mid + (args.prefill_chunk + 1) / 2)
+    print(f"mixed steps: + one request feeding {args.prefill_chunk}-token chunks from position {args.prefill_ctx}: "
+          f"{flops / 1e12:.2f} TFLOP of prefill attention per step beside the decode rows")
 kv_bytes = args.model_layers * args.seqs * (2 * ctx_mid * g.row_len * 4 + 2 * g.n_heads * g.head_dim * 4 + 3 * g.row_len * 4)
 print(f"decode batch{' (hipGraph replay)' if args.graph else ''}: {args.seqs} requests x ctx {args.ctx}, {args.model_layers} layer calls per step: "
       f"{dt * 1e3:8.3f} ms/step  {args.seqs / dt:10.0f} tokens/s  attention path {kv_bytes / dt / 1e9:7.1f} GB/s "
