@@ -368,14 +368,24 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     if (!live)
         return; // dead waves exist only in groups of 8 kv-waves, which have no second barrier (parts == 1)
 
-    // this wave's share of the chunk: whole steps, contiguous
-    int w0 = t0, w1 = t1;
+    // this wave's share of the chunk: whole steps
+    int w0 = t0, w1 = t1, stride = kStepTokens;
+    int nsteps = (t1 - t0 + kStepTokens - 1) / kStepTokens;
     if (parts > 1) {
-        const int per = ((t1 - t0 + kStepTokens - 1) / kStepTokens + parts - 1) / parts * kStepTokens;
+#ifdef NVK_TOKEN_SPLIT_CONTIGUOUS // A/B build: each part takes one contiguous run of steps
+        const int per = (nsteps + parts - 1) / parts * kStepTokens;
         w0            = min(t1, t0 + part * per);
         w1            = min(t1, w0 + per);
+        nsteps        = (w1 - w0 + kStepTokens - 1) / kStepTokens;
+#else
+        // steps dealt round-robin: at any moment the workgroup's waves stream neighbouring rows, the access
+        // pattern of a workgroup whose waves are the kv-heads of one row
+        w0     = t0 + part * kStepTokens;
+        stride = parts * kStepTokens;
+        nsteps = nsteps > part ? (nsteps - part + parts - 1) / parts : 0;
+#endif
     }
-    const bool has_tokens = w0 < w1;
+    const bool has_tokens = nsteps > 0;
 
     // pre-scale q into the exp2 domain
 #pragma unroll
@@ -485,23 +495,22 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     const std::integral_constant<bool, false> body;
     const std::integral_constant<bool, true>  tail;
     if (has_tokens) {
-        const int   nsteps = (w1 - w0 + kStepTokens - 1) / kStepTokens;
         Tile        ta, tb;
         int         k = 0;
         load_tile(ta, w0);
         for (; k + 2 < nsteps; k += 2) {
-            load_tile(tb, w0 + (k + 1) * kStepTokens);
-            consume_tile(ta, w0 + k * kStepTokens, body);
-            load_tile(ta, w0 + (k + 2) * kStepTokens);
-            consume_tile(tb, w0 + (k + 1) * kStepTokens, body);
+            load_tile(tb, w0 + (k + 1) * stride);
+            consume_tile(ta, w0 + k * stride, body);
+            load_tile(ta, w0 + (k + 2) * stride);
+            consume_tile(tb, w0 + (k + 1) * stride, body);
         }
         if (nsteps - k == 2) {
-            load_tile(tb, w0 + (k + 1) * kStepTokens);
-            consume_tile(ta, w0 + k * kStepTokens, body);
-            consume_tile(tb, w0 + (k + 1) * kStepTokens, tail);
+            load_tile(tb, w0 + (k + 1) * stride);
+            consume_tile(ta, w0 + k * stride, body);
+            consume_tile(tb, w0 + (k + 1) * stride, tail);
         }
         else {
-            consume_tile(ta, w0 + k * kStepTokens, tail);
+            consume_tile(ta, w0 + k * stride, tail);
         }
     }
 
