@@ -126,6 +126,32 @@ int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_h
                                 const float *v_rows, const int *block_tables, int max_blocks, const int *chunk_starts,
                                 const int *chunk_lens, float rope_theta, int ptr_kind, void *stream);
 
+/* ------------------------------------------- producing q / k / v on the device --
+ * SURVEY.md 8f row f1, second half: the rows the RoPE + append + attention entry points consume are made
+ * on the GPU, so a layer's attention input never crosses PCIe.  All pointers are DEVICE pointers on
+ * `device`; asynchronous on `stream` (NULL = that device's null stream); nothing is allocated.  fp32
+ * throughout; sums are associated differently from the reference's serial loops (tolerance, not bits).
+ *
+ * nvk_batch_rms_norm_device   out[b][i] = in[b][i] * rms_b * weight[i], rms_b = 1/sqrtf(sum_i in[b][i]^2/dim + eps)
+ *   ref: BatchOps::batch_rms_norm, experimental/chunked_prefill/batch_ops.hpp:58-76 = Ops::rms_norm per row,
+ *        include/ops/normalization.hpp:13-23 (eps 1e-5f there).  out may alias in.
+ * nvk_batch_matmul_device     out[b][i] = dot(in[b], weight[i]); weight [out_dim, in_dim] row-major
+ *   ref: BatchOps::batch_matmul, batch_ops.hpp:8-23 = Ops::matmul per row, include/ops/linear.hpp:12-22.
+ *        in_dim a multiple of 4, in/weight 16-byte aligned.  At most 32 rows: the weights are streamed once
+ *        (HBM-bound); more: 128x128 tiles on fp32 MFMA.
+ * nvk_qkv_project_device      the head of a layer, include/core/model.hpp:161-166 (forward_chunk:
+ *        model_chunked.hpp:57-77): xb = rms_norm(x, rms_weight); q = wq.xb, k = wk.xb, v = wv.xb in ONE
+ *        launch.  x [batch, dim]; xb [batch, dim] scratch (rms_weight NULL: x is used as it is and xb may be
+ *        NULL); wq [q_dim, dim], wk / wv [kv_dim, dim]; q [batch, q_dim], k / v [batch, kv_dim] -- the
+ *        layouts nvk_pool_rope_append_batch / _chunks take. */
+int nvk_batch_rms_norm_device(float *out_dev, const float *in_dev, const float *weight_dev, int batch_size, int dim,
+                              float eps, int device, void *stream);
+int nvk_batch_matmul_device(float *out_dev, const float *in_dev, const float *weight_dev, int batch_size, int in_dim,
+                            int out_dim, int device, void *stream);
+int nvk_qkv_project_device(float *q_dev, float *k_dev, float *v_dev, const float *x_dev, float *xb_dev,
+                           const float *rms_weight_dev, const float *wq_dev, const float *wk_dev, const float *wv_dev,
+                           int batch_size, int dim, int q_dim, int kv_dim, float rms_eps, int device, void *stream);
+
 /* Whole-block transfers, host pointers, [block_size, n_kv_heads, head_dim] floats each. */
 int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const float *k_block,
                           const float *v_block);

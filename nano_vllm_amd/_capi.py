@@ -75,6 +75,10 @@ SIGNATURES = {
     "nvk_pool_rope_append_chunks": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp,
                                               C.c_float, C.c_int, _vp]),
     "nvk_prefill": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int]),
+    "nvk_batch_rms_norm_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
+    "nvk_batch_matmul_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "nvk_qkv_project_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_float, C.c_int, _vp]),
     "nvk_prefill_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "nvk_pool_upload_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "nvk_pool_download_block": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),

@@ -11,6 +11,7 @@ outputs; the fixtures are data only (no reference source in any form).
   F2  tests/golden/attention_cases.npz         single-sequence paged_attention outputs
   F3  (same file) standard_attention outputs on the same rows (paged == contiguous)
   F6  tests/golden/prefill_cases.npz           chunked_attention outputs (experimental/chunked_prefill)
+  F7  tests/golden/qkv_cases.npz               Ops::rms_norm + Ops::matmul (q/k/v projections), = the BatchOps forms
   F4  tests/golden/tiny_llama_stream.npz       synthetic llama2.c checkpoint: token stream,
                                                logits, attention outputs, F5 block tables
 
@@ -31,7 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as ol  # noqa: E402
-from golden_defs import (ATTENTION_CASES, PREFILL_CASES, TINY_MODELS, BmCLib, attention_case_inputs,  # noqa: E402
+from golden_defs import (ATTENTION_CASES, PREFILL_CASES, QKV_CASES, TINY_MODELS, qkv_case_inputs, BmCLib, attention_case_inputs,  # noqa: E402
                          bm_trace_script, prefill_case_inputs, replay, write_checkpoint)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -85,6 +86,20 @@ def main():
         store[case["name"] + "/out"] = ol.ref_chunked_attention(q, k_lin, v_lin, case["start_pos"], case["n_kv_heads"])
     np.savez_compressed(os.path.join(GOLD, "prefill_cases.npz"), **store)
     print(f"F6: {len(PREFILL_CASES)} chunked-prefill cases")
+
+    # ---- F7: rms_norm + q/k/v projections (model.hpp:161-166) ----------------------
+    store = {}
+    for case in QKV_CASES:
+        x, g, wq, wk, wv = qkv_case_inputs(case)
+        xb = ol.batch_rms_norm(ol.REF.ref_rms_norm_rows, x, g)
+        assert np.array_equal(xb, ol.batch_rms_norm(ol.REF.ref_batch_rms_norm, x, g)), case["name"]
+        store[case["name"] + "/xb"] = xb
+        for key, w in (("q", wq), ("k", wk), ("v", wv)):
+            out = ol.batch_matmul(ol.REF.ref_matmul_rows, xb, w)
+            assert np.array_equal(out, ol.batch_matmul(ol.REF.ref_batch_matmul, xb, w)), case["name"]
+            store[case["name"] + "/" + key] = out
+    np.savez_compressed(os.path.join(GOLD, "qkv_cases.npz"), **store)
+    print(f"F7: {len(QKV_CASES)} rms_norm + qkv projection cases")
 
     # ---- F4 / F5 ---------------------------------------------------------------
     store = {}

@@ -654,6 +654,21 @@ static void rmsnorm(float *y, const float *x, const float *g, int n) /* ops/norm
         y[i] = x[i] * r * g[i];
 }
 
+/* The batched forms, BatchOps::batch_rms_norm / batch_matmul (experimental/chunked_prefill/batch_ops.hpp:58-76,
+ * :8-23): the per-row operators above applied to every row, in row order.  Checker of nvk_batch_rms_norm_device,
+ * nvk_batch_matmul_device and nvk_qkv_project_device. */
+void oracle_batch_rms_norm(float *out, const float *in, const float *weight, int batch_size, int dim)
+{
+    for (int b = 0; b < batch_size; b++)
+        rmsnorm(out + (size_t)b * dim, in + (size_t)b * dim, weight, dim);
+}
+
+void oracle_batch_matmul(float *out, const float *in, const float *weight, int batch_size, int in_dim, int out_dim)
+{
+    for (int b = 0; b < batch_size; b++)
+        gemv(out + (size_t)b * out_dim, in + (size_t)b * in_dim, weight, in_dim, out_dim);
+}
+
 /* Restates Ops::apply_rope, include/ops/positional.hpp:13-39: pairs (i, i+1) of every
  * q-head and kv-head rotated in place by angle pos / theta^(i/head_dim). */
 void oracle_apply_rope(float *q, float *k, int pos, int head_dim, int n_heads, int n_kv_heads, float theta)

@@ -17,6 +17,8 @@
 //   Sampler (greedy branch)         include/core/sampler.hpp:24-29
 //   Ops::apply_rope                 include/ops/positional.hpp:13-39
 //   LlamaModelChunked::chunked_attention  experimental/chunked_prefill/model_chunked.hpp:167-224
+//   Ops::rms_norm, Ops::matmul      include/ops/normalization.hpp:13-23, include/ops/linear.hpp:12-22
+//   BatchOps::batch_rms_norm, batch_matmul  experimental/chunked_prefill/batch_ops.hpp:58-76, :8-23
 
 #include <cstdio>
 #include <cstring>
@@ -126,6 +128,30 @@ void ref_chunked_attention(float *out, const float *q, const float *key_cache, c
 void ref_apply_rope(float *q, float *k, int pos, int head_dim, int n_heads, int n_kv_heads, float theta)
 {
     Ops::apply_rope(q, k, pos, head_dim, n_heads, n_kv_heads, theta);
+}
+
+// Ops::rms_norm / Ops::matmul (include/ops/normalization.hpp:13-23, include/ops/linear.hpp:12-22) per row, and
+// BatchOps::batch_rms_norm / batch_matmul (experimental/chunked_prefill/batch_ops.hpp:58-76, :8-23)
+void ref_rms_norm_rows(float *out, const float *in, const float *weight, int batch_size, int dim)
+{
+    for (int b = 0; b < batch_size; b++)
+        Ops::rms_norm(out + (size_t)b * dim, in + (size_t)b * dim, weight, dim);
+}
+
+void ref_matmul_rows(float *out, const float *in, const float *weight, int batch_size, int in_dim, int out_dim)
+{
+    for (int b = 0; b < batch_size; b++)
+        Ops::matmul(out + (size_t)b * out_dim, in + (size_t)b * in_dim, weight, in_dim, out_dim);
+}
+
+void ref_batch_rms_norm(float *out, const float *in, const float *weight, int batch_size, int dim)
+{
+    BatchOps::batch_rms_norm(out, in, weight, batch_size, dim);
+}
+
+void ref_batch_matmul(float *out, const float *in, const float *weight, int batch_size, int in_dim, int out_dim)
+{
+    BatchOps::batch_matmul(out, in, weight, batch_size, in_dim, out_dim);
 }
 
 // ------------------------------------------------------------- BlockManager

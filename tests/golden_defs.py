@@ -78,6 +78,26 @@ def prefill_case_inputs(case):
     return q, k_lin, v_lin
 
 
+# F7: the head of a layer (model.hpp:161-166): rms_norm, then the q / k / v projections.  (batch, dim, q_dim, kv_dim)
+QKV_CASES = []
+for _i, (_B, _D, _QD, _KD) in enumerate([(1, 288, 288, 288), (5, 288, 288, 288), (3, 64, 40, 8), (33, 128, 96, 32),
+                                          (32, 512, 256, 64), (70, 256, 384, 128), (200, 96, 130, 30)]):
+    QKV_CASES.append({"name": f"b{_B}_d{_D}_q{_QD}_kv{_KD}", "index": _i, "batch": _B, "dim": _D, "q_dim": _QD,
+                      "kv_dim": _KD})
+
+
+def qkv_case_inputs(case):
+    """x [B, dim], rms weight [dim], wq [q_dim, dim], wk / wv [kv_dim, dim] of a QKV case (weights ~ U(-1,1)/sqrt(dim))."""
+    i, B, D, QD, KD = case["index"], case["batch"], case["dim"], case["q_dim"], case["kv_dim"]
+    x = (uniform(7000 + i, 0, B * D) * np.float32(2)).reshape(B, D)
+    g = uniform(7100 + i, 0, D) * np.float32(0.5) + np.float32(1)
+    sc = np.float32(1.0 / np.sqrt(D))
+    wq = (uniform(7200 + i, 0, QD * D) * sc).reshape(QD, D)
+    wk = (uniform(7300 + i, 0, KD * D) * sc).reshape(KD, D)
+    wv = (uniform(7400 + i, 0, KD * D) * sc).reshape(KD, D)
+    return x, g, wq, wk, wv
+
+
 def paged_from_contiguous(k_lin, v_lin, block_size, seed, spare=3):
     """The same rows behind a shuffled block table: returns (k_pool, v_pool, table)."""
     T, KV, hd = k_lin.shape

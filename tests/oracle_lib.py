@@ -44,6 +44,10 @@ def _load_oracle(path):
     lib.oracle_decode_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i]
     lib.oracle_apply_rope.restype = None
     lib.oracle_apply_rope.argtypes = [_vp, _vp, _i, _i, _i, _i, C.c_float]
+    lib.oracle_batch_rms_norm.restype = None
+    lib.oracle_batch_rms_norm.argtypes = [_vp, _vp, _vp, _i, _i]
+    lib.oracle_batch_matmul.restype = None
+    lib.oracle_batch_matmul.argtypes = [_vp, _vp, _vp, _i, _i, _i]
     lib.oracle_kv_append.restype = None
     lib.oracle_kv_append.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]
     lib.oracle_bm_create.restype = _vp
@@ -102,6 +106,14 @@ def _load_ref(path):
     if hasattr(lib, "ref_apply_rope"):
         lib.ref_apply_rope.restype = None
         lib.ref_apply_rope.argtypes = [_vp, _vp, _i, _i, _i, _i, C.c_float]
+    for name in ("ref_rms_norm_rows", "ref_batch_rms_norm"):
+        if hasattr(lib, name):
+            getattr(lib, name).restype = None
+            getattr(lib, name).argtypes = [_vp, _vp, _vp, _i, _i]
+    for name in ("ref_matmul_rows", "ref_batch_matmul"):
+        if hasattr(lib, name):
+            getattr(lib, name).restype = None
+            getattr(lib, name).argtypes = [_vp, _vp, _vp, _i, _i, _i]
     lib.ref_bm_create.restype = _vp
     lib.ref_bm_create.argtypes = [_i, _i]
     lib.ref_bm_destroy.restype = None
@@ -261,4 +273,22 @@ def oracle_paged_prefill(q, k_cache, v_cache, table, start_pos, block_size, n_kv
     att = np.empty(H * (start_pos + C_ + 1), np.float32)
     ORACLE.oracle_paged_prefill_attention(_p(out), _p(q), _p(k_cache), _p(v_cache), _p(table), _p(att), C_,
                                           int(start_pos), int(block_size), hd, H, int(n_kv_heads))
+    return out
+
+
+def batch_rms_norm(fn, x, weight):
+    """fn = ORACLE.oracle_batch_rms_norm / REF.ref_batch_rms_norm / REF.ref_rms_norm_rows; x [batch, dim]."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(weight, np.float32)
+    out = np.empty_like(x)
+    fn(_p(out), _p(x), _p(w), x.shape[0], x.shape[1])
+    return out
+
+
+def batch_matmul(fn, x, weight):
+    """fn = ORACLE.oracle_batch_matmul / REF.ref_batch_matmul / REF.ref_matmul_rows; x [batch, in], weight [out, in]."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(weight, np.float32)
+    out = np.empty((x.shape[0], w.shape[0]), np.float32)
+    fn(_p(out), _p(x), _p(w), x.shape[0], x.shape[1], w.shape[0])
     return out

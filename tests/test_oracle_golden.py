@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from golden_defs import (ATTENTION_CASES, PREFILL_CASES, TINY_MODELS, BmCLib, attention_case_inputs,
+from golden_defs import (ATTENTION_CASES, PREFILL_CASES, QKV_CASES, TINY_MODELS, qkv_case_inputs, BmCLib, attention_case_inputs,
                          paged_from_contiguous, prefill_case_inputs, replay, write_checkpoint)
 
 pytestmark = pytest.mark.skipif(ol.ORACLE is None, reason="oracle/libnvk_oracle.so not built (make oracle)")
@@ -62,6 +62,18 @@ def test_chunked_prefill_case_bit_exact(case, golden_dir):
     k_pool, v_pool, table = paged_from_contiguous(k_lin, v_lin, 16, 8000 + case["index"])
     paged = ol.oracle_paged_prefill(q, k_pool, v_pool, table, case["start_pos"], 16, case["n_kv_heads"])
     assert np.array_equal(paged.view(np.uint32), gold.view(np.uint32))  # paged == contiguous, per query
+
+
+@pytest.mark.parametrize("case", QKV_CASES, ids=[c["name"] for c in QKV_CASES])
+def test_qkv_projection_case_bit_exact(case, golden_dir):
+    """F7: Ops::rms_norm and the three Ops::matmul of model.hpp:161-166, recorded from the reference."""
+    gold = np.load(os.path.join(golden_dir, "qkv_cases.npz"))
+    x, g, wq, wk, wv = qkv_case_inputs(case)
+    xb = ol.batch_rms_norm(ol.ORACLE.oracle_batch_rms_norm, x, g)
+    assert np.array_equal(xb.view(np.uint32), gold[case["name"] + "/xb"].view(np.uint32))
+    for key, w in (("q", wq), ("k", wk), ("v", wv)):
+        out = ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, xb, w)
+        assert np.array_equal(out.view(np.uint32), gold[case["name"] + "/" + key].view(np.uint32)), key
 
 
 @pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])

@@ -88,3 +88,17 @@ def test_chunked_prefill_attention_bit_exact():
         for bq in (0, C_ - 1):
             one = ol.standard_attention(ol.REF.ref_standard_attention, q[bq], k, v, start + bq, hd, H, KV, T)
             assert np.array_equal(one.view(np.uint32), b[bq].view(np.uint32))
+
+
+def test_rms_norm_and_matmul_bit_exact():
+    """oracle_batch_rms_norm / oracle_batch_matmul vs Ops::rms_norm / Ops::matmul per row and vs the BatchOps forms."""
+    for seed, (B, D, N) in enumerate([(1, 288, 288), (3, 64, 40), (5, 4096, 96), (33, 100, 7), (2, 8, 1)]):
+        x = (uniform(600 + seed, 0, B * D) * np.float32(2)).reshape(B, D)
+        g = (uniform(610 + seed, 0, D) + np.float32(1.5))
+        w = (uniform(620 + seed, 0, N * D) * np.float32(0.1)).reshape(N, D)
+        a = ol.batch_rms_norm(ol.ORACLE.oracle_batch_rms_norm, x, g)
+        for fn in (ol.REF.ref_rms_norm_rows, ol.REF.ref_batch_rms_norm):
+            assert np.array_equal(a.view(np.uint32), ol.batch_rms_norm(fn, x, g).view(np.uint32))
+        m = ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, a, w)
+        for fn in (ol.REF.ref_matmul_rows, ol.REF.ref_batch_matmul):
+            assert np.array_equal(m.view(np.uint32), ol.batch_matmul(fn, a, w).view(np.uint32))
