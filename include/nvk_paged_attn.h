@@ -330,6 +330,13 @@ int nvk_batch_begin_step_chunks(nvk_batch *batch, const int *request_ids, const 
 int nvk_batch_step_rows(const nvk_batch *batch);
 int nvk_batch_layer(nvk_batch *batch, int layer, float *q_dev, const float *k_rows_dev, const float *v_rows_dev,
                     float *out_dev, float rope_theta, void *stream);
+/* The same layer from the hidden state (include/core/model.hpp:161-221 in one call): x [rows, dim] ->
+ * rms_norm (rms_weight NULL: x is already normalised) -> q / k / v projections (nvk_qkv_project_device) ->
+ * RoPE + append + attention as nvk_batch_layer.  q / k / v live in scratch rows the batch keeps (grown, with a
+ * device synchronisation, the first time a step needs more). */
+int nvk_batch_layer_hidden(nvk_batch *batch, int layer, const float *x_dev, int dim, const float *rms_weight_dev,
+                           const float *wq_dev, const float *wk_dev, const float *wv_dev, float rms_eps, float *out_dev,
+                           float rope_theta, void *stream);
 int nvk_batch_end_step(nvk_batch *batch);
 /* out2 = {steps that uploaded whole tables, steps that only patched new entries} */
 int nvk_batch_stats(const nvk_batch *batch, long long *out2);

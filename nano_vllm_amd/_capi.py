@@ -115,6 +115,7 @@ SIGNATURES = {
     "nvk_batch_begin_step": (C.c_int, [_vp, _i, C.c_int, C.c_int, _vp]),
     "nvk_batch_begin_step_chunks": (C.c_int, [_vp, _i, _i, C.c_int, C.c_int, _vp]),
     "nvk_batch_step_rows": (C.c_int, [_vp]),
+    "nvk_batch_layer_hidden": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_float, _vp]),
     "nvk_batch_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp]),
     "nvk_batch_end_step": (C.c_int, [_vp]),
     "nvk_batch_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),

@@ -70,6 +70,15 @@ class DecodeBatch:
                                               _devptr(v_rows_dev), _devptr(out_dev), float(rope_theta),
                                               _devptr(stream)))
 
+    def layer_hidden(self, layer: int, x_dev, dim: int, rms_weight_dev, wq_dev, wk_dev, wv_dev, out_dev,
+                     rope_theta: float = 10000.0, rms_eps: float = 1e-5, stream=None) -> None:
+        """The layer from the hidden state (model.hpp:161-221): rms_norm + q/k/v projections + RoPE + append +
+        attention; x [rows, dim] on the device, weights [.., dim] row-major on the device."""
+        _capi.check(_capi.lib.nvk_batch_layer_hidden(self._h, int(layer), _devptr(x_dev), int(dim),
+                                                     _devptr(rms_weight_dev), _devptr(wq_dev), _devptr(wk_dev),
+                                                     _devptr(wv_dev), float(rms_eps), _devptr(out_dev),
+                                                     float(rope_theta), _devptr(stream)))
+
     def end_step(self) -> None:
         _capi.check(_capi.lib.nvk_batch_end_step(self._h))
 

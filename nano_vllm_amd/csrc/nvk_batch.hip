@@ -104,6 +104,10 @@ struct nvk_batch
     hipEvent_t staged = nullptr; // the last copies out of the pinned buffers have finished
     nvk_plan  *plan   = nullptr;
 
+    // q / k / v / normalised-x rows of nvk_batch_layer_hidden (grown on demand, kept)
+    float *h_q = nullptr, *h_k = nullptr, *h_v = nullptr, *h_xb = nullptr;
+    size_t h_rows = 0, h_dim = 0, h_qdim = 0;
+
     // counters for tests and tuning: how the tables reached the device
     long long full_uploads = 0, patch_steps = 0;
 };
@@ -131,6 +135,9 @@ void release(nvk_batch *b)
         if (p)
             (void)hipHostFree(p);
     for (int *p : {b->d_tables, b->d_pos, b->d_ctx, b->d_patches})
+        if (p)
+            (void)hipFree(p);
+    for (float *p : {b->h_q, b->h_k, b->h_v, b->h_xb})
         if (p)
             (void)hipFree(p);
     if (b->staged)
@@ -569,6 +576,46 @@ int nvk_batch_layer(nvk_batch *b, int layer, float *q_dev, const float *k_rows_d
         return rc;
     // attention over pos + 1 tokens: the new token attends to itself (model.hpp:221, :397)
     return nvk_decode_planned(b->pool, layer, b->plan, q_dev, b->d_tables, b->max_blocks, out_dev, (void *)st);
+}
+
+int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim, const float *rms_weight_dev,
+                           const float *wq_dev, const float *wk_dev, const float *wv_dev, float rms_eps, float *out_dev,
+                           float rope_theta, void *stream)
+{
+    if (!b || !b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_layer_hidden: no step in flight (call nvk_batch_begin_step)");
+    if (b->step_ids.empty())
+        return NVK_OK;
+    if (!x_dev || dim <= 0 || !wq_dev || !wk_dev || !wv_dev || !out_dev)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_layer_hidden: bad arguments");
+    const int rows = nvk_batch_step_rows(b);
+    if (rows < 0)
+        return rows;
+    const size_t qdim = (size_t)b->n_heads * b->head_dim;
+    DeviceScope  scope(b->device);
+    hipStream_t  st = stream_or_pool(b, stream);
+    if ((size_t)rows > b->h_rows || (size_t)dim > b->h_dim || qdim > b->h_qdim) {
+        // grow the scratch rows: earlier launches may still use the old ones
+        HIP_TRY(hipDeviceSynchronize());
+        for (float **p : {&b->h_q, &b->h_k, &b->h_v, &b->h_xb})
+            if (*p) {
+                (void)hipFree(*p);
+                *p = nullptr;
+            }
+        b->h_rows = b->h_dim = b->h_qdim = 0;
+        const size_t r = std::max((size_t)rows, (size_t)b->max_seqs), d = (size_t)dim;
+        HIP_TRY(hipMalloc((void **)&b->h_q, r * qdim * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&b->h_k, r * b->row_len * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&b->h_v, r * b->row_len * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&b->h_xb, r * d * sizeof(float)));
+        b->h_rows = r, b->h_dim = d, b->h_qdim = qdim;
+    }
+    // model.hpp:161-166: xb = rms_norm(x), q / k / v = wq / wk / wv . xb -- then :169-221 as nvk_batch_layer
+    int rc = nvk_qkv_project_device(b->h_q, b->h_k, b->h_v, x_dev, b->h_xb, rms_weight_dev, wq_dev, wk_dev, wv_dev, rows,
+                                    dim, (int)qdim, b->row_len, rms_eps, b->device, (void *)st);
+    if (rc != NVK_OK)
+        return rc;
+    return nvk_batch_layer(b, layer, b->h_q, b->h_k, b->h_v, out_dev, rope_theta, (void *)st);
 }
 
 int nvk_batch_end_step(nvk_batch *b)

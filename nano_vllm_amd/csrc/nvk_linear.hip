@@ -9,14 +9,16 @@
 // row-major and out[b][i] = dot(in[b], weight[i]): C = A . W^T with both operands contiguous along
 // the contraction ("NT"), all fp32.
 //
-// Two kernels behind one dispatcher:
-//   * nvk_gemm_nt_kernel     -- more than 32 rows: a 128x128 tile per workgroup on
-//                               v_mfma_f32_32x32x2_f32 (exact fp32 products and sums, an fmaf chain
-//                               per output), bound by the fp32 MFMA rate;
-//   * nvk_gemm_skinny_kernel -- at most 32 rows (decode batches of a few requests): the weights are
-//                               streamed once, 32 output columns per workgroup, the contraction
-//                               split over the workgroup's 8 waves; bound by HBM (the weight bytes).
-// Both take up to three (weight, out) segments in one launch, so wq, wk and wv share the launch and
+// Three kernels behind one dispatcher (thresholds measured, profiles/r01_qkv_projection.log):
+//   * nvk_gemv_kernel        -- 1 or 2 rows (the reference's own case: Ops::matmul is a GEMV): weights
+//                               streamed once and multiplied on the vector ALUs; bound by HBM;
+//   * nvk_gemm_skinny_kernel -- up to 96 rows (decode batches of a few requests): 32 x 32 output tiles on
+//                               v_mfma_f32_32x32x2_f32, the contraction split over the workgroup's 8 waves;
+//                               weights streamed once per 32 rows; HBM / MFMA about level;
+//   * nvk_gemm_nt_kernel     -- more rows: 64 x 64 or 128 x 128 tiles per workgroup on the same MFMA
+//                               (exact fp32 products and sums, an fmaf chain per output); bound by the
+//                               fp32 MFMA rate.
+// All take up to three (weight, out) segments in one launch, so wq, wk and wv share the launch and
 // the normalised activations.  gfx950 only; no CPU path.
 
 #include <hip/hip_runtime.h>
@@ -32,6 +34,20 @@
             return nvk::fail(e__ == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "%s failed: %s (%s:%d)", #expr,  \
                              hipGetErrorString(e__), __FILE__, __LINE__);                                              \
     } while (0)
+
+#ifndef NVK_K_ROTATE
+#define NVK_K_ROTATE 1 // A/B switch for the rotated walk over the contraction dimension
+#endif
+#ifndef NVK_GEMM_FORCE_TILE
+#define NVK_GEMM_FORCE_TILE 0 // tuning: 128 or 64 pins the tiled kernel's tile, 0 = by workgroup count
+#endif
+#ifndef NVK_GEMV_MAX_ROWS
+#define NVK_GEMV_MAX_ROWS 2 // up to here the vector-ALU GEMV kernel (measured: from 3 rows on its registers allow one
+                            // workgroup per CU and the MFMA kernel is as fast); at most 8, 0 switches it off
+#endif
+#ifndef NVK_SKINNY_MAX_ROWS
+#define NVK_SKINNY_MAX_ROWS 96 // up to here the weight-streaming MFMA kernel (32-row tiles), above it the tiled one
+#endif
 
 namespace nvk {
 
@@ -111,20 +127,18 @@ __global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ o
     }
 }
 
-// ---- C = A . W^T, more than 32 rows: 128 x 128 tiles on fp32 MFMA ---------------------------------
-// 4 waves as 2 x 2, each a 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs).
-// A and W tiles of 32 contraction steps go global -> registers -> LDS (row stride 36 floats: the
-// lanes' ds_read_b128 fall in distinct banks), double-buffered, one barrier per step.  The
+// ---- C = A . W^T, many rows: BM x BN tiles (128 x 128 or 64 x 64) on fp32 MFMA ---------------------
+// 4 waves as 2 x 2, each a (BM/2) x (BN/2) sub-tile of 32 x 32 MFMA tiles (64 accumulator VGPRs at 128 x 128).
+// A and W tiles of BK contraction steps go global -> registers (two tiles ahead) -> LDS (row stride BK + 4
+// floats: the lanes' ds_read_b128 fall in distinct banks), double-buffered, one barrier per step.  The
 // instruction's two k lanes are re-associated over four MFMAs so a lane's operands are one float4:
 // lane (j, half) of MFMA e supplies element k = 8c + 4*half + e of its row.
 // Tile ids are dealt so that the row tiles of one column tile run on one XCD at about the same time
 // (ids go round-robin over the 8 XCDs): the weight tile is then read from HBM once and met in that L2.
-constexpr int kGemmBK  = 32;
-constexpr int kGemmLds = kGemmBK + 4;
-
-__global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams p)
+template <int BM, int BN, int BK> __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams p)
 {
-    constexpr int BM = 128, BN = 128;
+    constexpr int TA = BM / 64, TB = BN / 64; // 32 x 32 MFMA tiles per wave along the rows / the columns
+    constexpr int kGemmBK = BK, kGemmLds = BK + 4, KV = BK / 32; // KV: float4 per thread per tile row pass
     extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [2][BM + BN][kGemmLds]
 
     const int span = 8 * p.m_tiles;
@@ -149,86 +163,131 @@ __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams 
     for (int i = 0; i < BN / 32; i++)
         wrow[i] = sg.w + (int64_t)min(n0 + lr + 32 * i, sg.n - 1) * p.k + lc;
 
-    float4 ra[BM / 32], rb[BN / 32];
-    auto   fetch = [&](int k0) {
-        const bool inside = k0 + lc < p.k; // k % 4 == 0: a float4 is wholly inside or outside
-#pragma unroll
-        for (int i = 0; i < BM / 32; i++)
-            ra[i] = inside ? *reinterpret_cast<const float4 *>(arow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < BN / 32; i++)
-            rb[i] = inside ? *reinterpret_cast<const float4 *>(wrow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // two tiles ahead in registers (HBM latency is longer than one tile's MFMAs when a SIMD has one wave)
+    struct Regs
+    {
+        float4 a[BM / 32][KV], b[BN / 32][KV];
     };
-    auto stash = [&](int buf) {
+    Regs r0, r1;
+    auto fetch = [&](Regs &r, int k0) {
+#pragma unroll
+        for (int u = 0; u < KV; u++) {
+            const bool inside = k0 + 32 * u + lc < p.k; // k % 4 == 0: a float4 is wholly inside or outside
+#pragma unroll
+            for (int i = 0; i < BM / 32; i++)
+                r.a[i][u] = inside ? *reinterpret_cast<const float4 *>(arow[i] + k0 + 32 * u)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < BN / 32; i++)
+                r.b[i][u] = inside ? *reinterpret_cast<const float4 *>(wrow[i] + k0 + 32 * u)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](const Regs &r, int buf) {
         float *sa = s_mem + buf * (BM + BN) * kGemmLds, *sb = sa + BM * kGemmLds;
 #pragma unroll
-        for (int i = 0; i < BM / 32; i++)
-            *reinterpret_cast<float4 *>(sa + (lr + 32 * i) * kGemmLds + lc) = ra[i];
+        for (int u = 0; u < KV; u++) {
 #pragma unroll
-        for (int i = 0; i < BN / 32; i++)
-            *reinterpret_cast<float4 *>(sb + (lr + 32 * i) * kGemmLds + lc) = rb[i];
+            for (int i = 0; i < BM / 32; i++)
+                *reinterpret_cast<float4 *>(sa + (lr + 32 * i) * kGemmLds + 32 * u + lc) = r.a[i][u];
+#pragma unroll
+            for (int i = 0; i < BN / 32; i++)
+                *reinterpret_cast<float4 *>(sb + (lr + 32 * i) * kGemmLds + 32 * u + lc) = r.b[i][u];
+        }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TA][TB];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < TA; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < TB; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 acc[a][b][r] = 0.f;
 
-    const int nk = (p.k + kGemmBK - 1) / kGemmBK;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk)
-            fetch((kt + 1) * kGemmBK);
-        const float *sa = s_mem + (kt & 1) * (BM + BN) * kGemmLds + (wm * 64 + j) * kGemmLds + 4 * half;
-        const float *sb = s_mem + (kt & 1) * (BM + BN) * kGemmLds + (BM + wn * 64 + j) * kGemmLds + 4 * half;
-#pragma unroll
-        for (int c = 0; c < kGemmBK / 8; c++) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(sa + 8 * c);
-            const float4 a1 = *reinterpret_cast<const float4 *>(sa + 32 * kGemmLds + 8 * c);
-            const float4 b0 = *reinterpret_cast<const float4 *>(sb + 8 * c);
-            const float4 b1 = *reinterpret_cast<const float4 *>(sb + 32 * kGemmLds + 8 * c);
 #define NVK_MFMA4(A, B, ACC)                                                                                           \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B.x, ACC, 0, 0, 0);                                                \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B.y, ACC, 0, 0, 0);                                                \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, ACC, 0, 0, 0);                                                \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, ACC, 0, 0, 0);
-            NVK_MFMA4(a0, b0, acc[0][0])
-            NVK_MFMA4(a0, b1, acc[0][1])
-            NVK_MFMA4(a1, b0, acc[1][0])
-            NVK_MFMA4(a1, b1, acc[1][1])
+    auto multiply = [&](int buf) {
+        const float *sa = s_mem + buf * (BM + BN) * kGemmLds + (wm * (BM / 2) + j) * kGemmLds + 4 * half;
+        const float *sb = s_mem + buf * (BM + BN) * kGemmLds + (BM + wn * (BN / 2) + j) * kGemmLds + 4 * half;
+        // operands of chunk c + 1 are read from LDS while chunk c is multiplied
+        float4 av[2][TA], bv[2][TB];
+        auto   operands = [&](int slot, int c) {
+#pragma unroll
+            for (int a = 0; a < TA; a++)
+                av[slot][a] = *reinterpret_cast<const float4 *>(sa + 32 * a * kGemmLds + 8 * c);
+#pragma unroll
+            for (int b = 0; b < TB; b++)
+                bv[slot][b] = *reinterpret_cast<const float4 *>(sb + 32 * b * kGemmLds + 8 * c);
+        };
+        operands(0, 0);
+#pragma unroll
+        for (int c = 0; c < kGemmBK / 8; c++) {
+            if (c + 1 < kGemmBK / 8)
+                operands((c + 1) & 1, c + 1);
+#pragma unroll
+            for (int a = 0; a < TA; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++) {
+                    NVK_MFMA4(av[c & 1][a], bv[c & 1][b], acc[a][b])
+                }
         }
+    };
+
+    const int nk  = (p.k + kGemmBK - 1) / kGemmBK;
+    // the walk over k starts at a tile that depends on the column tile (see nvk_gemm_skinny_kernel: HBM channels)
+    const int rot = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
+    auto      k_at = [&](int kt) { return ((kt + rot) % nk) * kGemmBK; };
+    // tile kt sits in LDS buffer kt & 1; at the top of step kt the registers r[(kt + 1) & 1] hold (or await)
+    // tile kt + 1 and r[kt & 1] is free for tile kt + 2
+    fetch(r0, k_at(0));
+    if (nk > 1)
+        fetch(r1, k_at(1));
+    stash(r0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk)
+            fetch(r0, k_at(kt + 2));
+        multiply(0);
         if (kt + 1 < nk)
-            stash((kt + 1) & 1); // the other buffer: every wave left it before the previous barrier
+            stash(r1, 1); // the other buffer: every wave left it before the previous barrier
         __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 3 < nk)
+                fetch(r1, k_at(kt + 3));
+            multiply(1);
+            if (kt + 2 < nk)
+                stash(r0, 0);
+            __syncthreads();
+        }
     }
 
     // D[row][col]: col = lane & 31, register r holds row (r & 3) + 8 * (r >> 2) + 4 * half
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < TA; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int col = n0 + wn * 64 + 32 * b + j;
+        for (int b = 0; b < TB; b++) {
+            const int col = n0 + wn * (BN / 2) + 32 * b + j;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = m0 + wm * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int row = m0 + wm * (BM / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < p.m && col < sg.n)
                     sg.out[(int64_t)row * sg.ldo + col] = acc[a][b][r];
             }
         }
 }
 
-// ---- C = A . W^T, at most 32 rows: stream the weights once ----------------------------------------
-// One workgroup = 32 output columns (32 weight rows), 8 waves, the contraction dealt round-robin over
-// the waves in steps of 64.  Every wave is on its own: it brings its 32 x 64 weight tile and the
-// matching activation tile global -> registers (the whole next step in flight while the current one
-// is multiplied) -> its private LDS region -> MFMA operands; no barrier until the waves' partial
-// 32 x 32 tiles meet in LDS at the end.  Rows past m are computed on clamped addresses and dropped.
+// ---- C = A . W^T, few rows: stream the weights once -----------------------------------------------
+// One workgroup = a 32 x 32 output tile (32 weight rows), 8 waves, the contraction dealt round-robin
+// over the waves in steps of 64.  Every wave is on its own: it brings its 32 x 64 weight tile and the
+// matching activation tile global -> registers -> its private LDS region -> MFMA operands; the weight
+// tiles of the next TWO steps are in flight while the current one is multiplied (HBM latency is longer
+// than one step's 32 MFMAs), the activations (L2-resident) one step ahead.  No barrier until the waves'
+// partial tiles meet in LDS at the end.  Rows past m are computed on clamped addresses and dropped.
+// With more than 32 rows the row tiles of one column tile are dealt to one XCD (as in the tiled kernel).
 constexpr int kSkinnyBK  = 64;
 constexpr int kSkinnyLds = kSkinnyBK + 4;
 constexpr int kSkinnyWaves = 8;
@@ -236,7 +295,12 @@ constexpr int kSkinnyWaves = 8;
 __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [waves][2][32][kSkinnyLds]
-    const int nt = blockIdx.x;
+    const int span = 8 * p.m_tiles;
+    const int rem  = blockIdx.x % span;
+    const int nt   = blockIdx.x / span * 8 + rem % 8;
+    const int m0   = rem / 8 * 32;
+    if (nt >= p.n_tiles)
+        return;
     const LinearSeg sg = segment_of(p, nt);
     const int       n0 = (nt - sg.tile0) * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -244,45 +308,74 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     const int lr = lane >> 4, lc = (lane & 15) * 4; // 4 rows x 64 k per load instruction
 
     float *sa = s_mem + wave * 2 * 32 * kSkinnyLds, *sb = sa + 32 * kSkinnyLds;
-    const float *arow[8], *wrow[8];
+    int    aoff[8], woff[8]; // float offsets of this lane's eight rows (the host checked they fit an int)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        arow[i] = p.a + (int64_t)min(lr + 4 * i, p.m - 1) * p.lda + lc;
-        wrow[i] = sg.w + (int64_t)min(n0 + lr + 4 * i, sg.n - 1) * p.k + lc;
+        aoff[i] = min(m0 + lr + 4 * i, p.m - 1) * p.lda + lc;
+        woff[i] = min(n0 + lr + 4 * i, sg.n - 1) * p.k + lc;
     }
-    float4 ra[8], rb[8];
-    auto   fetch = [&](int k0) {
+    float4 rx[8], rw0[8], rw1[8];
+    auto   fetch_w = [&](float4(&r)[8], int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            rb[i] = inside ? load_stream(wrow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto fetch_x = [&](int k0) {
+        const bool inside = k0 + lc < p.k;
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            ra[i] = inside ? *reinterpret_cast<const float4 *>(arow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[i] = inside ? *reinterpret_cast<const float4 *>(p.a + aoff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](const float4(&r)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            *reinterpret_cast<float4 *>(sa + (lr + 4 * i) * kSkinnyLds + lc) = rx[i];
+            *reinterpret_cast<float4 *>(sb + (lr + 4 * i) * kSkinnyLds + lc) = r[i];
+        }
     };
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++)
         acc[r] = 0.f;
-
-    const int nk = (p.k + kSkinnyBK - 1) / kSkinnyBK;
-    if (wave < nk)
-        fetch(wave * kSkinnyBK);
-    for (int kt = wave; kt < nk; kt += kSkinnyWaves) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            *reinterpret_cast<float4 *>(sa + (lr + 4 * i) * kSkinnyLds + lc) = ra[i];
-            *reinterpret_cast<float4 *>(sb + (lr + 4 * i) * kSkinnyLds + lc) = rb[i];
-        }
-        if (kt + kSkinnyWaves < nk)
-            fetch((kt + kSkinnyWaves) * kSkinnyBK);
-        const float *pa = sa + j * kSkinnyLds + 4 * half, *pb = sb + j * kSkinnyLds + 4 * half;
+    const float *pa = sa + j * kSkinnyLds + 4 * half, *pb = sb + j * kSkinnyLds + 4 * half;
+    auto         multiply = [&]() {
 #pragma unroll
         for (int c = 0; c < kSkinnyBK / 8; c++) {
             const float4 a0 = *reinterpret_cast<const float4 *>(pa + 8 * c);
             const float4 b0 = *reinterpret_cast<const float4 *>(pb + 8 * c);
             NVK_MFMA4(a0, b0, acc)
+        }
+    };
+
+    const int nk    = (p.k + kSkinnyBK - 1) / kSkinnyBK;
+    const int steps = nk > wave ? (nk - wave + kSkinnyWaves - 1) / kSkinnyWaves : 0; // this wave's share
+    // Every workgroup starts the contraction somewhere else (a function of its column tile only, so an output's
+    // summation order does not depend on its row): rows of W are in_dim * 4 bytes apart, and workgroups walking k
+    // in lockstep would all be asking the same few HBM channels for the same 256-byte column of every row.
+    const int rot   = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
+    auto      k_of  = [&](int s) { return ((wave + s * kSkinnyWaves + rot) % nk) * kSkinnyBK; };
+    if (steps > 0) {
+        fetch_w(rw0, k_of(0));
+        fetch_x(k_of(0));
+    }
+    if (steps > 1)
+        fetch_w(rw1, k_of(1));
+    for (int s = 0; s < steps; s += 2) {
+        stash(rw0);
+        if (s + 2 < steps)
+            fetch_w(rw0, k_of(s + 2));
+        if (s + 1 < steps)
+            fetch_x(k_of(s + 1));
+        multiply();
+        if (s + 1 < steps) {
+            stash(rw1);
+            if (s + 3 < steps)
+                fetch_w(rw1, k_of(s + 3));
+            if (s + 2 < steps)
+                fetch_x(k_of(s + 2));
+            multiply();
         }
     }
 #undef NVK_MFMA4
@@ -301,8 +394,8 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
             const float4 v = *reinterpret_cast<const float4 *>(s_mem + w * 2 * 32 * kSkinnyLds + r * 64 + l4);
             sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
         }
-        const int h   = l4 >> 5;                               // the four lanes share a half
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int h   = l4 >> 5; // the four lanes share a half
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int col = n0 + (l4 & 31);
         if (row < p.m) {
             float *o = sg.out + (int64_t)row * sg.ldo + col;
@@ -315,6 +408,100 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
                 if (col + 3 < sg.n) o[3] = sum.w;
             }
         }
+    }
+}
+
+// ---- C = A . W^T, at most 8 rows: the reference's own case (one token: Ops::matmul is a GEMV) -------
+// HBM-bound: every weight byte is read once and multiplied on the vector ALUs (an MFMA tile padded to 32
+// rows would cost as much time as the stream itself).  One workgroup = 16 output columns (16 weight rows),
+// 8 waves dealing the contraction round-robin in steps of 64; a lane holds a float4 of four weight rows
+// per step (256 contiguous bytes per row and instruction), two steps in flight, and the matching float4
+// of every activation row (L2-resident).  Per lane partial sums -> DPP row sum over the 16 lanes of a
+// weight row -> the eight waves meet in LDS.  An output's summation order depends on k only.
+constexpr int kGemvWaves = 8, kGemvCols = 16, kGemvBK = 64;
+
+template <int M> __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
+{
+    __shared__ float s_red[kGemvWaves][M][kGemvCols];
+    const int       nt = blockIdx.x;
+    const LinearSeg sg = segment_of(p, nt);
+    const int       n0 = (nt - sg.tile0) * kGemvCols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane >> 4, lc = (lane & 15) * 4;
+
+    int woff[4], xoff[M];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        woff[i] = min(n0 + lr + 4 * i, sg.n - 1) * p.k + lc;
+#pragma unroll
+    for (int m = 0; m < M; m++)
+        xoff[m] = min(m, p.m - 1) * p.lda + lc;
+
+    float4 rw0[4], rw1[4], rx0[M], rx1[M];
+    auto   fetch = [&](float4(&w)[4], float4(&x)[M], int k0) {
+        const bool inside = k0 + lc < p.k;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            w[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < M; m++)
+            x[m] = inside ? *reinterpret_cast<const float4 *>(p.a + xoff[m] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float acc[M][4];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            acc[m][i] = 0.f;
+    auto consume = [&](const float4(&w)[4], const float4(&x)[M]) {
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                acc[m][i] = fmaf(w[i].x, x[m].x, acc[m][i]);
+                acc[m][i] = fmaf(w[i].y, x[m].y, acc[m][i]);
+                acc[m][i] = fmaf(w[i].z, x[m].z, acc[m][i]);
+                acc[m][i] = fmaf(w[i].w, x[m].w, acc[m][i]);
+            }
+    };
+
+    const int nk    = (p.k + kGemvBK - 1) / kGemvBK;
+    const int steps = nk > wave ? (nk - wave + kGemvWaves - 1) / kGemvWaves : 0;
+    const int rot   = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
+    auto      k_of  = [&](int s) { return ((wave + s * kGemvWaves + rot) % nk) * kGemvBK; };
+    if (steps > 0)
+        fetch(rw0, rx0, k_of(0));
+    if (steps > 1)
+        fetch(rw1, rx1, k_of(1));
+    for (int s = 0; s < steps; s += 2) {
+        consume(rw0, rx0);
+        if (s + 2 < steps)
+            fetch(rw0, rx0, k_of(s + 2));
+        if (s + 1 < steps) {
+            consume(rw1, rx1);
+            if (s + 3 < steps)
+                fetch(rw1, rx1, k_of(s + 3));
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = acc[m][i]; // sum over the 16 lanes that share weight row lr + 4i
+            v += __shfl_xor(v, 1), v += __shfl_xor(v, 2), v += __shfl_xor(v, 4), v += __shfl_xor(v, 8);
+            if ((lane & 15) == 0)
+                s_red[wave][m][lr + 4 * i] = v;
+        }
+    __syncthreads();
+    if (tid < M * kGemvCols) {
+        const int m = tid / kGemvCols, c = tid % kGemvCols;
+        float     sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < kGemvWaves; w++)
+            sum += s_red[w][m][c];
+        if (m < p.m && n0 + c < sg.n)
+            sg.out[(int64_t)m * sg.ldo + n0 + c] = sum;
     }
 }
 
@@ -359,11 +546,33 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: in_dim=%d must be a multiple of 4", who, in_dim);
     if (!aligned16(in))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: the activations must be 16-byte aligned", who);
+    if ((long long)batch * in_dim > 0x7fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %d x %d activations exceed 2^31 floats", who, batch, in_dim);
+    for (int s = 0; s < nseg; s++)
+        if ((long long)n[s] * in_dim > 0x7fffffffLL)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "%s: a %d x %d weight exceeds 2^31 floats", who, n[s], in_dim);
     nvk::LinearParams p;
     p.a = in, p.m = batch, p.k = in_dim, p.lda = in_dim;
-    const bool skinny = batch <= 32;
-    const int  bn     = skinny ? 32 : 128;
-    long long  tiles  = 0;
+    const bool gemv   = batch <= NVK_GEMV_MAX_ROWS;
+    const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
+    // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
+    int bm = 128, bn = 128;
+    if (!gemv && !skinny) {
+        long long t128 = 0;
+        for (int s = 0; s < nseg; s++)
+            t128 += (n[s] + 127) / 128;
+        t128 *= (batch + 127) / 128;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        // measured (profiles/r01_qkv_projection.log): two 128 x 128 workgroups fit a CU, and a launch that is not
+        // at least three full rounds of them loses more to the ragged last round than 64 x 64 tiles lose to their
+        // four times higher LDS and L2 traffic per flop
+        if (NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
+            bm = bn = 64;
+    }
+    else
+        bn = gemv ? nvk::kGemvCols : 32;
+    long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
         if (n[s] == 0)
@@ -377,8 +586,23 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     if (p.nseg == 0 || batch == 0)
         return NVK_OK;
     p.n_tiles = (int)tiles;
-    if (skinny) {
+    if (gemv) {
         p.m_tiles = 1;
+        const dim3 grid((unsigned)tiles), block(64 * nvk::kGemvWaves);
+        if (batch == 1)
+            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<1>, grid, block, 0, st, p);
+        else if (batch == 2)
+            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<2>, grid, block, 0, st, p);
+#if NVK_GEMV_MAX_ROWS > 2
+        else if (batch <= 4)
+            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<4>, grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<8>, grid, block, 0, st, p);
+#endif
+    }
+    else if (skinny) {
+        p.m_tiles = (batch + 31) / 32;
+        const long long wgs = p.m_tiles == 1 ? tiles : (tiles + 7) / 8 * 8 * p.m_tiles;
         const size_t lds = (size_t)nvk::kSkinnyWaves * 2 * 32 * nvk::kSkinnyLds * sizeof(float);
         static bool  opted[64]; // > 64 KiB of dynamic LDS needs the attribute, once per device
         if (!opted[device & 63]) {
@@ -386,21 +610,35 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             opted[device & 63] = true;
         }
-        hipLaunchKernelGGL(nvk::nvk_gemm_skinny_kernel, dim3((unsigned)tiles), dim3(64 * nvk::kSkinnyWaves), lds, st, p);
+        hipLaunchKernelGGL(nvk::nvk_gemm_skinny_kernel, dim3((unsigned)wgs), dim3(64 * nvk::kSkinnyWaves), lds, st, p);
     }
     else {
-        p.m_tiles = (batch + 127) / 128;
+        p.m_tiles = (batch + bm - 1) / bm;
         const long long wgs = (tiles + 7) / 8 * 8 * p.m_tiles;
         if (wgs > 0x7fffffffLL)
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
-        const size_t lds = (size_t)2 * 256 * nvk::kGemmLds * sizeof(float);
-        static bool  opted[64];
-        if (!opted[device & 63]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)nvk::nvk_gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-            opted[device & 63] = true;
+        const int    bk  = bm == 128 ? 32 : (batch <= 256 ? 64 : 32); // 64 x 64: fewer barriers while waves are few
+        const size_t lds = (size_t)2 * (bm + bn) * (bk + 4) * sizeof(float);
+        if (bm == 128) {
+            static bool opted[64];
+            if (!opted[device & 63]) {
+                HIP_TRY(hipFuncSetAttribute((const void *)nvk::nvk_gemm_nt_kernel<128, 128, 32>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                opted[device & 63] = true;
+            }
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<128, 128, 32>), dim3((unsigned)wgs), dim3(256), lds, st, p);
         }
-        hipLaunchKernelGGL(nvk::nvk_gemm_nt_kernel, dim3((unsigned)wgs), dim3(256), lds, st, p);
+        else if (bk == 64) {
+            static bool opted[64];
+            if (!opted[device & 63]) {
+                HIP_TRY(hipFuncSetAttribute((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                opted[device & 63] = true;
+            }
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<64, 64, 64>), dim3((unsigned)wgs), dim3(256), lds, st, p);
+        }
+        else
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<64, 64, 32>), dim3((unsigned)wgs), dim3(256), lds, st, p);
     }
     HIP_TRY(hipGetLastError());
     return NVK_OK;

@@ -210,3 +210,54 @@ def test_chunked_prefill_beside_decode_in_one_batch():
             step += 1
         assert not running and bm.get_num_free_blocks() == nb
         assert steps_with_both >= 3  # the schedule really mixes decode rows and prefill chunks in one step
+
+
+def test_layer_from_the_hidden_state():
+    """nvk_batch_layer_hidden = model.hpp:161-221 for every row of a mixed step: rms_norm, q/k/v projections, RoPE,
+    append, attention -- against the checker doing the same per token on the host."""
+    L, H, KV, hd, bs, D = 2, 8, 2, 64, 8, 192
+    nb, max_blocks = 64, 8
+    rng = np.random.default_rng(91)
+    sc = np.float32(1.0 / np.sqrt(D))
+    W = [dict(g=rng.random(D, dtype=np.float32) + np.float32(0.5),
+              wq=rng.standard_normal((H * hd, D), dtype=np.float32) * sc,
+              wk=rng.standard_normal((KV * hd, D), dtype=np.float32) * sc,
+              wv=rng.standard_normal((KV * hd, D), dtype=np.float32) * sc) for _ in range(L)]
+    host_k = np.zeros((L, nb, bs, KV, hd), np.float32)
+    host_v = np.zeros_like(host_k)
+    bm = nv.BlockManager(nb, bs)
+    fed = {1: 0, 2: 0, 3: 0}
+    schedule = [([1, 2], [19, 5]), ([2, 1, 3], [1, 1, 21]), ([1, 2, 3], [1, 1, 1]), ([1, 2, 3], [1, 1, 1])]
+    with nv.PagedKVPool(L, nb, bs, KV, hd) as pool, nv.DecodeBatch(pool, bm, 4, max_blocks) as batch:
+        dW = [{k: DeviceArray(v) for k, v in w.items()} for w in W]
+        for rid in fed:
+            batch.add_request(rid)
+        for ids, chunks in schedule:
+            rows = batch.begin_step_chunks(ids, chunks, H)
+            for layer in range(L):
+                x = rng.standard_normal((rows, D), dtype=np.float32)
+                outd = DeviceArray(np.full((rows, H, hd), np.nan, np.float32))
+                w = dW[layer]
+                batch.layer_hidden(layer, DeviceArray(x), D, w["g"], w["wq"], w["wk"], w["wv"], outd, 10000.0)
+                pool.synchronize()
+                got = outd.numpy()
+                xb = ol.batch_rms_norm(ol.ORACLE.oracle_batch_rms_norm, x, W[layer]["g"])
+                q, k, v = (ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, xb, W[layer][n]) for n in ("wq", "wk", "wv"))
+                r0 = 0
+                for rid, c in zip(ids, chunks):
+                    table = np.asarray(batch.request_blocks(rid), np.int32)
+                    rq = []
+                    for b in range(c):
+                        pos = fed[rid] + b
+                        wq_, wk_ = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q[r0 + b], k[r0 + b], pos, hd, H, KV, 10000.0)
+                        host_k[layer, table[pos // bs], pos % bs] = wk_.reshape(KV, hd)
+                        host_v[layer, table[pos // bs], pos % bs] = v[r0 + b].reshape(KV, hd)
+                        rq.append(wq_.reshape(H, hd))
+                    for b in range(c):
+                        pos = fed[rid] + b
+                        want = ol.oracle_paged_attention(rq[b], host_k[layer], host_v[layer], table, pos + 1, bs, hd, H, KV)
+                        assert close(got[r0 + b], want), (ids, layer, rid, b, float(np.abs(got[r0 + b] - want).max()))
+                    r0 += c
+            batch.end_step()
+            for rid, c in zip(ids, chunks):
+                fed[rid] += c
