@@ -12,9 +12,9 @@
 // Three kernels behind one dispatcher (thresholds measured, profiles/r01_qkv_projection.log):
 //   * nvk_gemv_kernel        -- 1 or 2 rows (the reference's own case: Ops::matmul is a GEMV): weights
 //                               streamed once and multiplied on the vector ALUs; bound by HBM;
-//   * nvk_gemm_skinny_kernel -- up to 96 rows (decode batches of a few requests): 32 x 32 output tiles on
-//                               v_mfma_f32_32x32x2_f32, the contraction split over the workgroup's 8 waves;
-//                               weights streamed once per 32 rows; HBM / MFMA about level;
+//   * nvk_gemm_skinny_kernel -- up to 96 rows (decode batches of a few requests): 16 x 16 (up to 16 rows) or
+//                               32 x 32 output tiles on fp32 MFMA, the contraction split over the workgroup's
+//                               8 waves; weights streamed once per tile of rows; HBM / MFMA about level;
 //   * nvk_gemm_nt_kernel     -- more rows: 64 x 64 or 128 x 128 tiles per workgroup on the same MFMA
 //                               (exact fp32 products and sums, an fmaf chain per output); bound by the
 //                               fp32 MFMA rate.
@@ -43,7 +43,10 @@
 #endif
 #ifndef NVK_GEMV_MAX_ROWS
 #define NVK_GEMV_MAX_ROWS 2 // up to here the vector-ALU GEMV kernel (measured: from 3 rows on its registers allow one
-                            // workgroup per CU and the MFMA kernel is as fast); at most 8, 0 switches it off
+                            // workgroup per CU and the MFMA kernel is as fast); at most 4, 0 switches it off
+#endif
+#ifndef NVK_SKINNY16_MAX_ROWS
+#define NVK_SKINNY16_MAX_ROWS 16 // up to here the weight-streaming kernel uses 16 x 16 MFMA tiles (0: always 32 x 32)
 #endif
 #ifndef NVK_SKINNY_MAX_ROWS
 #define NVK_SKINNY_MAX_ROWS 96 // up to here the weight-streaming MFMA kernel (32-row tiles), above it the tiled one
@@ -292,60 +295,80 @@ constexpr int kSkinnyBK  = 64;
 constexpr int kSkinnyLds = kSkinnyBK + 4;
 constexpr int kSkinnyWaves = 8;
 
-__global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// T = 32: 32 x 32 tiles on v_mfma_f32_32x32x2_f32.  T = 16 (at most 16 rows): 16 x 16 tiles on
+// v_mfma_f32_16x16x4_f32 -- half the MFMA cycles spent on padding rows, twice the workgroups, half the LDS.
+template <int T> __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [waves][2][32][kSkinnyLds]
+    constexpr int R = T / 4; // tile rows per lane: a load instruction covers 4 rows x 64 k
+    extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [waves][2][T][kSkinnyLds]
     const int span = 8 * p.m_tiles;
     const int rem  = blockIdx.x % span;
     const int nt   = blockIdx.x / span * 8 + rem % 8;
-    const int m0   = rem / 8 * 32;
+    const int m0   = rem / 8 * T;
     if (nt >= p.n_tiles)
         return;
     const LinearSeg sg = segment_of(p, nt);
-    const int       n0 = (nt - sg.tile0) * 32;
+    const int       n0 = (nt - sg.tile0) * T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, half = lane >> 5;
-    const int lr = lane >> 4, lc = (lane & 15) * 4; // 4 rows x 64 k per load instruction
+    const int j = lane & (T - 1), part = lane / T; // MFMA operand row / column, and which k lanes of the instruction
+    const int lr = lane >> 4, lc = (lane & 15) * 4;
 
-    float *sa = s_mem + wave * 2 * 32 * kSkinnyLds, *sb = sa + 32 * kSkinnyLds;
-    int    aoff[8], woff[8]; // float offsets of this lane's eight rows (the host checked they fit an int)
+    float *sa = s_mem + wave * 2 * T * kSkinnyLds, *sb = sa + T * kSkinnyLds;
+    int    aoff[R], woff[R]; // float offsets of this lane's rows (the host checked they fit an int)
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < R; i++) {
         aoff[i] = min(m0 + lr + 4 * i, p.m - 1) * p.lda + lc;
         woff[i] = min(n0 + lr + 4 * i, sg.n - 1) * p.k + lc;
     }
-    float4 rx[8], rw0[8], rw1[8];
-    auto   fetch_w = [&](float4(&r)[8], int k0) {
+    float4 rx[R], rw0[R], rw1[R];
+    auto   fetch_w = [&](float4(&r)[R], int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < R; i++)
             r[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto fetch_x = [&](int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < R; i++)
             rx[i] = inside ? *reinterpret_cast<const float4 *>(p.a + aoff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto stash = [&](const float4(&r)[8]) {
+    auto stash = [&](const float4(&r)[R]) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < R; i++) {
             *reinterpret_cast<float4 *>(sa + (lr + 4 * i) * kSkinnyLds + lc) = rx[i];
             *reinterpret_cast<float4 *>(sb + (lr + 4 * i) * kSkinnyLds + lc) = r[i];
         }
     };
 
-    f32x16 acc;
+    constexpr int NACC = T == 32 ? 16 : 4; // accumulator registers of one tile
+    f32x16 acc32;
+    f32x4  acc16;
 #pragma unroll
     for (int r = 0; r < 16; r++)
-        acc[r] = 0.f;
-    const float *pa = sa + j * kSkinnyLds + 4 * half, *pb = sb + j * kSkinnyLds + 4 * half;
-    auto         multiply = [&]() {
+        acc32[r] = 0.f;
 #pragma unroll
-        for (int c = 0; c < kSkinnyBK / 8; c++) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(pa + 8 * c);
-            const float4 b0 = *reinterpret_cast<const float4 *>(pb + 8 * c);
-            NVK_MFMA4(a0, b0, acc)
+    for (int r = 0; r < 4; r++)
+        acc16[r] = 0.f;
+    // lane (j, part) of MFMA e supplies element 4 * part + e of the chunk (8 wide at T = 32, 16 wide at T = 16)
+    const float *pa = sa + j * kSkinnyLds + 4 * part, *pb = sb + j * kSkinnyLds + 4 * part;
+    auto         multiply = [&]() {
+        constexpr int CH = T == 32 ? 8 : 16;
+#pragma unroll
+        for (int c = 0; c < kSkinnyBK / CH; c++) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(pa + CH * c);
+            const float4 b0 = *reinterpret_cast<const float4 *>(pb + CH * c);
+            if constexpr (T == 32) {
+                NVK_MFMA4(a0, b0, acc32)
+            }
+            else {
+                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc16, 0, 0, 0);
+                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc16, 0, 0, 0);
+                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc16, 0, 0, 0);
+                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc16, 0, 0, 0);
+            }
         }
     };
 
@@ -380,23 +403,24 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     }
 #undef NVK_MFMA4
 
-    // the waves' partial tiles meet in LDS (each wave's own region, 16 x 64 floats); then 256 of the
-    // 512 threads add the eight partials of four outputs each, in wave order
+    // the waves' partial tiles meet in LDS (each wave's own region, NACC x 64 floats); then NACC x 16 threads add
+    // the eight partials of four outputs each, in wave order.  D[row][col]: col = lane % T; register r of lane
+    // part p holds row (r & 3) + 8 * (r >> 2) + 4 * p at T = 32, row 4 * p + r at T = 16.
 #pragma unroll
-    for (int r = 0; r < 16; r++)
-        sa[r * 64 + lane] = acc[r]; // the wave's own region: its operand reads are behind it
+    for (int r = 0; r < NACC; r++)
+        sa[r * 64 + lane] = T == 32 ? acc32[r] : acc16[r & 3]; // the wave's own region: its operand reads are behind it
     __syncthreads();
-    if (tid < 256) {
+    if (tid < NACC * 16) {
         const int r = tid >> 4, l4 = (tid & 15) * 4; // register r, lanes l4 .. l4 + 3
         float4    sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int w = 0; w < kSkinnyWaves; w++) {
-            const float4 v = *reinterpret_cast<const float4 *>(s_mem + w * 2 * 32 * kSkinnyLds + r * 64 + l4);
+            const float4 v = *reinterpret_cast<const float4 *>(s_mem + w * 2 * T * kSkinnyLds + r * 64 + l4);
             sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
         }
-        const int h   = l4 >> 5; // the four lanes share a half
-        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int col = n0 + (l4 & 31);
+        const int pt  = l4 / T; // the four lanes share a part
+        const int row = m0 + (T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * pt : 4 * pt + r);
+        const int col = n0 + (l4 & (T - 1));
         if (row < p.m) {
             float *o = sg.out + (int64_t)row * sg.ldo + col;
             if (col + 3 < sg.n && (sg.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.out) & 15) == 0))
@@ -418,9 +442,9 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
 // per step (256 contiguous bytes per row and instruction), two steps in flight, and the matching float4
 // of every activation row (L2-resident).  Per lane partial sums -> DPP row sum over the 16 lanes of a
 // weight row -> the eight waves meet in LDS.  An output's summation order depends on k only.
-constexpr int kGemvWaves = 8, kGemvCols = 16, kGemvBK = 64;
+constexpr int kGemvWaves = 8, kGemvBK = 64;
 
-template <int M> __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
+template <int M, int kGemvCols> __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
 {
     __shared__ float s_red[kGemvWaves][M][kGemvCols];
     const int       nt = blockIdx.x;
@@ -429,35 +453,36 @@ template <int M> __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_ker
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane >> 4, lc = (lane & 15) * 4;
 
-    int woff[4], xoff[M];
+    constexpr int R = kGemvCols / 4; // weight rows per lane
+    int woff[R], xoff[M];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < R; i++)
         woff[i] = min(n0 + lr + 4 * i, sg.n - 1) * p.k + lc;
 #pragma unroll
     for (int m = 0; m < M; m++)
         xoff[m] = min(m, p.m - 1) * p.lda + lc;
 
-    float4 rw0[4], rw1[4], rx0[M], rx1[M];
-    auto   fetch = [&](float4(&w)[4], float4(&x)[M], int k0) {
+    float4 rw0[R], rw1[R], rx0[M], rx1[M];
+    auto   fetch = [&](float4(&w)[R], float4(&x)[M], int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < R; i++)
             w[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int m = 0; m < M; m++)
             x[m] = inside ? *reinterpret_cast<const float4 *>(p.a + xoff[m] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    float acc[M][4];
+    float acc[M][R];
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < R; i++)
             acc[m][i] = 0.f;
-    auto consume = [&](const float4(&w)[4], const float4(&x)[M]) {
+    auto consume = [&](const float4(&w)[R], const float4(&x)[M]) {
 #pragma unroll
         for (int m = 0; m < M; m++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < R; i++) {
                 acc[m][i] = fmaf(w[i].x, x[m].x, acc[m][i]);
                 acc[m][i] = fmaf(w[i].y, x[m].y, acc[m][i]);
                 acc[m][i] = fmaf(w[i].z, x[m].z, acc[m][i]);
@@ -487,7 +512,7 @@ template <int M> __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_ker
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < R; i++) {
             float v = acc[m][i]; // sum over the 16 lanes that share weight row lr + 4i
             v += __shfl_xor(v, 1), v += __shfl_xor(v, 2), v += __shfl_xor(v, 4), v += __shfl_xor(v, 8);
             if ((lane & 15) == 0)
@@ -571,7 +596,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             bm = bn = 64;
     }
     else
-        bn = gemv ? nvk::kGemvCols : 32;
+        bn = gemv ? (batch <= 2 ? 16 : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
     long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
@@ -590,27 +615,32 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         p.m_tiles = 1;
         const dim3 grid((unsigned)tiles), block(64 * nvk::kGemvWaves);
         if (batch == 1)
-            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<1>, grid, block, 0, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, 16>), grid, block, 0, st, p);
         else if (batch == 2)
-            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<2>, grid, block, 0, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, 16>), grid, block, 0, st, p);
 #if NVK_GEMV_MAX_ROWS > 2
-        else if (batch <= 4)
-            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<4>, grid, block, 0, st, p);
         else
-            hipLaunchKernelGGL(nvk::nvk_gemv_kernel<8>, grid, block, 0, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<4, 32>), grid, block, 0, st, p);
 #endif
     }
     else if (skinny) {
-        p.m_tiles = (batch + 31) / 32;
+        const int t = bn; // 16 x 16 tiles for at most 16 rows, else 32 x 32
+        p.m_tiles = (batch + t - 1) / t;
         const long long wgs = p.m_tiles == 1 ? tiles : (tiles + 7) / 8 * 8 * p.m_tiles;
-        const size_t lds = (size_t)nvk::kSkinnyWaves * 2 * 32 * nvk::kSkinnyLds * sizeof(float);
-        static bool  opted[64]; // > 64 KiB of dynamic LDS needs the attribute, once per device
-        if (!opted[device & 63]) {
-            HIP_TRY(hipFuncSetAttribute((const void *)nvk::nvk_gemm_skinny_kernel,
+        if (wgs > 0x7fffffffLL)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
+        const size_t lds = (size_t)nvk::kSkinnyWaves * 2 * t * nvk::kSkinnyLds * sizeof(float);
+        static bool  opted[64][2]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
+        if (!opted[device & 63][t == 32]) {
+            HIP_TRY(hipFuncSetAttribute(t == 32 ? (const void *)nvk::nvk_gemm_skinny_kernel<32>
+                                                : (const void *)nvk::nvk_gemm_skinny_kernel<16>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            opted[device & 63] = true;
+            opted[device & 63][t == 32] = true;
         }
-        hipLaunchKernelGGL(nvk::nvk_gemm_skinny_kernel, dim3((unsigned)wgs), dim3(64 * nvk::kSkinnyWaves), lds, st, p);
+        if (t == 32)
+            hipLaunchKernelGGL(nvk::nvk_gemm_skinny_kernel<32>, dim3((unsigned)wgs), dim3(64 * nvk::kSkinnyWaves), lds, st, p);
+        else
+            hipLaunchKernelGGL(nvk::nvk_gemm_skinny_kernel<16>, dim3((unsigned)wgs), dim3(64 * nvk::kSkinnyWaves), lds, st, p);
     }
     else {
         p.m_tiles = (batch + bm - 1) / bm;
