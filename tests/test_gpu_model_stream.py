@@ -1,0 +1,101 @@
+"""The reference's greedy token streams (fixture F4, recorded from LlamaModel::forward + the greedy sampler) reproduced
+with every matmul, RMSNorm, RoPE, KV append and attention of the forward pass on the GPU through the C ABI
+(include/core/model.hpp:150-247): per layer nvk_batch_layer_hidden (rms_norm + q/k/v + RoPE + append + paged
+attention), nvk_batch_matmul_device for wo / w_gate / w_up / w_down / lm_head, nvk_batch_rms_norm_device for the
+FFN and final norms.  Only the residual adds and SwiGLU (elementwise, model.hpp:227-239) run in numpy here.
+
+Bar: identical greedy streams and teacher-forced argmax (BASELINE.json north_star: "identical greedy-decoded token
+streams"); logits within 2e-3 + 1e-4 relative of the reference's (the per-op 1e-4 bar compounds over the layers)."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_defs import TINY_MODELS, checkpoint_tensors
+
+pytestmark = pytest.mark.gpu
+
+
+class DeviceModel:
+    def __init__(self, nv, DA, spec):
+        self.nv, self.DA, self.spec = nv, DA, spec
+        D, L, H, KV = spec["dim"], spec["n_layers"], spec["n_heads"], spec["n_kv_heads"]
+        self.hd = D // H
+        t = dict(checkpoint_tensors(spec))
+        self.tok_emb = t["tok_emb"].reshape(spec["vocab_size"], D)
+        per = lambda name, rows, cols: [DA(t[name].reshape(L, rows, cols)[l]) for l in range(L)]
+        self.rms_att = [DA(t["rms_att"].reshape(L, D)[l]) for l in range(L)]
+        self.rms_ffn = [DA(t["rms_ffn"].reshape(L, D)[l]) for l in range(L)]
+        self.wq, self.wk, self.wv = per("wq", H * self.hd, D), per("wk", KV * self.hd, D), per("wv", KV * self.hd, D)
+        self.wo = per("wo", D, H * self.hd)
+        self.w_gate, self.w_up = per("w_gate", spec["hidden_dim"], D), per("w_up", spec["hidden_dim"], D)
+        self.w_down = per("w_down", D, spec["hidden_dim"])
+        self.rms_final = DA(t["rms_final"])
+        self.lm_head = DA(t["tok_emb"] if spec["shared"] else t["lm_head"])  # shared-classifier rule, model.hpp:349-356
+        self.bm = nv.BlockManager(spec["num_blocks"], spec["block_size"])
+        self.pool = nv.PagedKVPool(L, spec["num_blocks"], spec["block_size"], KV, self.hd)
+        self.batch = nv.DecodeBatch(self.pool, self.bm, 1, (spec["max_seq_len"] + spec["block_size"] - 1) // spec["block_size"])
+        self.batch.add_request(0)
+
+    def close(self):
+        self.batch.close()
+        self.pool.close()
+
+    def matmul(self, x, w_dev, out_dim):
+        out = self.DA(np.empty((1, out_dim), np.float32))
+        self.nv.batch_matmul_device(out, self.DA(x.reshape(1, -1)), w_dev, 1, x.size, out_dim, stream=self.pool.stream)
+        self.pool.synchronize()
+        return out.numpy().reshape(-1)
+
+    def rms_norm(self, x, w_dev):
+        out = self.DA(np.empty((1, x.size), np.float32))
+        self.nv.batch_rms_norm_device(out, self.DA(x.reshape(1, -1)), w_dev, 1, x.size, stream=self.pool.stream)
+        self.pool.synchronize()
+        return out.numpy().reshape(-1)
+
+    def forward(self, token):
+        s, nv = self.spec, self.nv
+        D, H, Hd = s["dim"], s["n_heads"], s["hidden_dim"]
+        x = self.tok_emb[token].copy()
+        self.batch.begin_step([0], H)
+        for l in range(s["n_layers"]):
+            att = self.DA(np.empty((1, H, self.hd), np.float32))
+            self.batch.layer_hidden(l, self.DA(x.reshape(1, D)), D, self.rms_att[l], self.wq[l], self.wk[l], self.wv[l], att)
+            self.pool.synchronize()
+            x = x + self.matmul(att.numpy().reshape(-1), self.wo[l], D)               # model.hpp:224-228
+            xb = self.rms_norm(x, self.rms_ffn[l])                                    # :231
+            gate, up = self.matmul(xb, self.w_gate[l], Hd), self.matmul(xb, self.w_up[l], Hd)
+            hb = (gate / (np.float32(1) + np.exp(-gate, dtype=np.float32))) * up      # Ops::swiglu, activation.hpp:34-40
+            x = x + self.matmul(hb.astype(np.float32), self.w_down[l], D)             # :235-239
+        self.batch.end_step()
+        return self.matmul(self.rms_norm(x, self.rms_final), self.lm_head, s["vocab_size"])  # :243-246
+
+
+@pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])
+def test_greedy_streams_with_the_forward_pass_on_the_gpu(spec, golden_dir):
+    import nano_vllm_amd as nv
+    from hipmem import DeviceArray
+
+    gold = np.load(os.path.join(golden_dir, "tiny_llama_stream.npz"))
+    n = spec["name"]
+    m = DeviceModel(nv, DeviceArray, spec)
+    try:
+        for pos, tok in enumerate(spec["forced_tokens"]):
+            logits = m.forward(int(tok))
+            want = gold[n + "/tf_logits"][pos]
+            assert np.all(np.abs(logits - want) <= 2e-3 + 1e-4 * np.abs(want)), (pos, float(np.abs(logits - want).max()))
+            assert int(np.argmax(logits)) == int(gold[n + "/tf_argmax"][pos]), pos
+    finally:
+        m.close()
+    m = DeviceModel(nv, DeviceArray, spec)
+    try:
+        prompt = spec["prompt_tokens"]
+        for tok in prompt[:-1]:
+            m.forward(int(tok))
+        tok, stream = int(prompt[-1]), []
+        for _ in range(spec["gen_steps"]):
+            tok = int(np.argmax(m.forward(tok)))  # sampler.hpp:27-29: first maximum
+            stream.append(tok)
+        assert stream == gold[n + "/greedy_stream"].tolist()
+    finally:
+        m.close()

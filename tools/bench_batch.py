@@ -27,6 +27,10 @@ ap.add_argument("--prefill-chunk", type=int, default=0,
                 help="mixed steps: one more request feeds a prompt chunk of this many tokens in every step "
                      "(nvk_batch_begin_step_chunks), beside the --seqs decoding requests")
 ap.add_argument("--prefill-ctx", type=int, default=0, help="tokens that request already holds when timing starts")
+ap.add_argument("--hidden", type=int, default=0, metavar="DIM",
+                help="start every layer call from the hidden state x [rows, DIM]: RMSNorm + q/k/v projections on the "
+                     "device (nvk_batch_layer_hidden), one weight set per pool layer (so the Infinity Cache does not "
+                     "hold them between calls)")
 ap.add_argument("--graph", action="store_true",
                 help="capture the step's layer loop in a hipGraph once and replay it (measurement of the device-side "
                      "time without host launch cost; lengths do not advance between replays)")
@@ -58,13 +62,30 @@ with nv.PagedKVPool(args.layers, nb, bs, g.n_kv_heads, g.head_dim) as pool, \
             batch.begin_step_chunks([PREFILL_ID], [args.prefill_ctx], g.n_heads)
             batch.end_step()
 
+    if args.hidden:
+        D = args.hidden
+        sc = np.float32(1.0 / np.sqrt(D))
+        xh = DeviceArray(wl.uniform(6, 0, rows * D).reshape(rows, D))
+        Wt = [dict(g=DeviceArray(wl.uniform(7 + 10 * l, 0, D) + np.float32(1.5)),
+                   wq=DeviceArray((wl.uniform(8 + 10 * l, 0, g.n_heads * g.head_dim * D) * sc)),
+                   wk=DeviceArray((wl.uniform(9 + 10 * l, 0, g.row_len * D) * sc)),
+                   wv=DeviceArray((wl.uniform(10 + 10 * l, 0, g.row_len * D) * sc))) for l in range(args.layers)]
+
+    def one_layer(i, stream=None):
+        if args.hidden:
+            w = Wt[i % args.layers]
+            batch.layer_hidden(i % args.layers, xh, args.hidden, w["g"], w["wq"], w["wk"], w["wv"], out, 10000.0,
+                               stream=stream)
+        else:
+            batch.layer(i % args.layers, q, k, v, out, 10000.0, stream=stream)
+
     def model_step(layer_calls):
         if args.prefill_chunk:
             batch.begin_step_chunks(ids + [PREFILL_ID], [1] * args.seqs + [args.prefill_chunk], g.n_heads)
         else:
             batch.begin_step(ids, g.n_heads)
         for i in range(layer_calls):
-            batch.layer(i % args.layers, q, k, v, out, 10000.0)
+            one_layer(i)
         batch.end_step()
 
     # bring every request to `ctx` tokens: the bookkeeping advances, the pool content is the synthetic fill
@@ -85,7 +106,7 @@ with nv.PagedKVPool(args.layers, nb, bs, g.n_kv_heads, g.head_dim) as pool, \
 
         def layers():
             for i in range(args.model_layers):
-                batch.layer(i % args.layers, q, k, v, out, 10000.0, stream=stream)
+                one_layer(i, stream)
 
         exe = stream.capture(layers)
         stream.launch(exe)
@@ -110,6 +131,9 @@ if args.prefill_chunk:
     print(f"mixed steps: + one request feeding {args.prefill_chunk}-token chunks from position {args.prefill_ctx}: "
           f"{flops / 1e12:.2f} TFLOP of prefill attention per step beside the decode rows")
 kv_bytes = args.model_layers * args.seqs * (2 * ctx_mid * g.row_len * 4 + 2 * g.n_heads * g.head_dim * 4 + 3 * g.row_len * 4)
+if args.hidden:
+    print(f"layers start from the hidden state (dim {args.hidden}): RMSNorm + q/k/v projections included in the step "
+          f"({2.0 * rows * (g.n_heads * g.head_dim + 2 * g.row_len) * args.hidden * args.model_layers / 1e12:.2f} TFLOP per step)")
 print(f"decode batch{' (hipGraph replay)' if args.graph else ''}: {args.seqs} requests x ctx {args.ctx}, {args.model_layers} layer calls per step: "
       f"{dt * 1e3:8.3f} ms/step  {args.seqs / dt:10.0f} tokens/s  attention path {kv_bytes / dt / 1e9:7.1f} GB/s "
       f"({100 * kv_bytes / dt / 8e12:4.1f}% of HBM peak)  bookkeeping-only steps {warm / args.ctx * 1e6:6.1f} us each  {st}")
