@@ -148,6 +148,10 @@ int nvk_batch_rms_norm_device(float *out_dev, const float *in_dev, const float *
                               float eps, int device, void *stream);
 int nvk_batch_matmul_device(float *out_dev, const float *in_dev, const float *weight_dev, int batch_size, int in_dim,
                             int out_dim, int device, void *stream);
+/* two products over the same activations in one launch (w_gate and w_up, include/core/model.hpp:232-233) */
+int nvk_batch_matmul2_device(float *out_a_dev, float *out_b_dev, const float *in_dev, const float *weight_a_dev,
+                             const float *weight_b_dev, int batch_size, int in_dim, int out_dim_a, int out_dim_b,
+                             int device, void *stream);
 int nvk_qkv_project_device(float *q_dev, float *k_dev, float *v_dev, const float *x_dev, float *xb_dev,
                            const float *rms_weight_dev, const float *wq_dev, const float *wk_dev, const float *wv_dev,
                            int batch_size, int dim, int q_dim, int kv_dim, float rms_eps, int device, void *stream);
@@ -338,8 +342,39 @@ int nvk_batch_layer_hidden(nvk_batch *batch, int layer, const float *x_dev, int 
                            const float *wq_dev, const float *wk_dev, const float *wv_dev, float rms_eps, float *out_dev,
                            float rope_theta, void *stream);
 int nvk_batch_end_step(nvk_batch *batch);
+/* Abandons the step in flight (a later call of the step failed): no request advances; blocks drawn for the step
+ * stay with their requests. */
+int nvk_batch_abort_step(nvk_batch *batch);
 /* out2 = {steps that uploaded whole tables, steps that only patched new entries} */
 int nvk_batch_stats(const nvk_batch *batch, long long *out2);
+
+/* ------------------------------------------------------ the model on the device --
+ * SURVEY.md 8f row f4 (checkpoint format) and the caller of the whole path: a llama2.c checkpoint resident in HBM
+ * and LlamaModel::forward (include/core/model.hpp:150-247) as batched steps, nothing but token ids and results
+ * crossing PCIe.  ref: LlamaModel::load / read_weights, include/core/model.hpp:118-148, 316-365 (7 x int32 header;
+ * tensors grouped by parameter type; lm_head shared with the embedding when the file ends early, :349-364);
+ * initialize_paged_attention, :249-277 (block_size / num_blocks: Config, :35-36); Sampler greedy branch,
+ * include/core/sampler.hpp:27-29.  Sampling with temperature is not offered: the reference seeds it from the clock
+ * (include/scheduler/request_processor.hpp:31-34), so only greedy streams are reproducible. */
+typedef struct nvk_model nvk_model;
+int nvk_model_load(const char *checkpoint_path, int block_size, int num_blocks, int max_seqs, int device,
+                   nvk_model **out_model);
+int nvk_model_destroy(nvk_model *model);
+/* out8 = {dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, max_seq_len, shared_classifier} */
+int nvk_model_config(const nvk_model *model, int *out8);
+int nvk_model_add_request(nvk_model *model, int request_id);
+int nvk_model_finish_request(nvk_model *model, int request_id); /* frees its KV blocks */
+int nvk_model_request_len(const nvk_model *model, int request_id);
+int nvk_model_free_blocks(const nvk_model *model);
+/* One model step: request i takes the next chunk_lens[i] >= 1 tokens of `tokens` (packed in list order; a prompt
+ * chunk, or 1 = decode).  next_tokens [n] (host, may be NULL) = greedy argmax after each request's last token;
+ * logits [n, vocab_size] (host, may be NULL) = the classifier's output for those rows.  Synchronous. */
+int nvk_model_step_chunks(nvk_model *model, const int *request_ids, const int *chunk_lens, const int *tokens, int n,
+                          int *next_tokens, float *logits);
+/* every chunk_lens[i] == 1 */
+int nvk_model_step(nvk_model *model, const int *request_ids, const int *tokens, int n, int *next_tokens, float *logits);
+/* LlamaModel::forward(token, pos) for ONE sequence (request 0, added on first use); pos must be its length */
+int nvk_model_forward(nvk_model *model, int token, int pos, float *logits);
 
 /* ---------------------------------------------------------- BlockManager --
  * Host-side allocator returning the same ids in the same order as

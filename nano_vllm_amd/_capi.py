@@ -77,6 +77,7 @@ SIGNATURES = {
     "nvk_prefill": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int]),
     "nvk_batch_rms_norm_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "nvk_batch_matmul_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "nvk_batch_matmul2_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "nvk_qkv_project_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, C.c_int, _vp]),
     "nvk_prefill_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
@@ -115,6 +116,17 @@ SIGNATURES = {
     "nvk_batch_begin_step": (C.c_int, [_vp, _i, C.c_int, C.c_int, _vp]),
     "nvk_batch_begin_step_chunks": (C.c_int, [_vp, _i, _i, C.c_int, C.c_int, _vp]),
     "nvk_batch_step_rows": (C.c_int, [_vp]),
+    "nvk_batch_abort_step": (C.c_int, [_vp]),
+    "nvk_model_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "nvk_model_destroy": (C.c_int, [_vp]),
+    "nvk_model_config": (C.c_int, [_vp, _i]),
+    "nvk_model_add_request": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_finish_request": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_request_len": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_free_blocks": (C.c_int, [_vp]),
+    "nvk_model_step_chunks": (C.c_int, [_vp, _i, _i, _i, C.c_int, _i, _f]),
+    "nvk_model_step": (C.c_int, [_vp, _i, _i, C.c_int, _i, _f]),
+    "nvk_model_forward": (C.c_int, [_vp, C.c_int, C.c_int, _f]),
     "nvk_batch_layer_hidden": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp, C.c_float, _vp]),
     "nvk_batch_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_float, _vp]),
     "nvk_batch_end_step": (C.c_int, [_vp]),

@@ -618,6 +618,17 @@ int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim,
     return nvk_batch_layer(b, layer, b->h_q, b->h_k, b->h_v, out_dev, rope_theta, (void *)st);
 }
 
+int nvk_batch_abort_step(nvk_batch *b)
+{
+    if (!b)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_abort_step: null batch");
+    // no request advances; blocks drawn for the step stay with their requests (the next step needs them anyway)
+    b->in_step        = false;
+    b->chunked        = false;
+    b->resident_valid = false;
+    return NVK_OK;
+}
+
 int nvk_batch_end_step(nvk_batch *b)
 {
     if (!b || !b->in_step)

@@ -708,6 +708,23 @@ int nvk_batch_matmul_device(float *out_dev, const float *in_dev, const float *we
                          "nvk_batch_matmul_device");
 }
 
+int nvk_batch_matmul2_device(float *out_a_dev, float *out_b_dev, const float *in_dev, const float *weight_a_dev,
+                             const float *weight_b_dev, int batch_size, int in_dim, int out_dim_a, int out_dim_b,
+                             int device, void *stream)
+{
+    if (batch_size < 0 || in_dim <= 0 || out_dim_a <= 0 || out_dim_b <= 0
+        || (batch_size > 0 && (!out_a_dev || !out_b_dev || !in_dev || !weight_a_dev || !weight_b_dev)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_matmul2_device: bad arguments");
+    int rc = check_device(device, "nvk_batch_matmul2_device");
+    if (rc != NVK_OK || batch_size == 0)
+        return rc;
+    DeviceScope        scope(device);
+    const float *const w[2]   = {weight_a_dev, weight_b_dev};
+    float *const       out[2] = {out_a_dev, out_b_dev};
+    const int          n[2]   = {out_dim_a, out_dim_b};
+    return launch_linear(in_dev, batch_size, in_dim, w, out, n, 2, device, (hipStream_t)stream, "nvk_batch_matmul2_device");
+}
+
 int nvk_qkv_project_device(float *q_dev, float *k_dev, float *v_dev, const float *x_dev, float *xb_dev,
                            const float *rms_weight_dev, const float *wq_dev, const float *wk_dev, const float *wv_dev,
                            int batch_size, int dim, int q_dim, int kv_dim, float rms_eps, int device, void *stream)

@@ -1,0 +1,516 @@
+// nvk_model.hip -- a llama2.c checkpoint resident on the device and its forward pass as batched steps
+// (the on-disk checkpoint format; and the caller of the whole path,
+// LlamaModel::forward, include/core/model.hpp:150-247).
+//
+// The file format is the reference's (include/core/model.hpp:118-148, 316-365): seven int32
+// (dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, max_seq_len), then fp32 tensors grouped by
+// parameter type -- token_embedding, rms_att[L], wq[L], wk[L], wv[L], wo[L], rms_ffn[L], w_gate[L],
+// w_down[L], w_up[L], rms_final, and lm_head only if the file still has vocab*dim floats left (else the
+// classifier shares the embedding table, :349-364).
+//
+// A step takes one token -- or a chunk of prompt tokens -- for each listed request and runs
+// model.hpp:150-247 for all their rows at once, everything on the device: embedding rows ->
+// per layer { nvk_batch_layer_hidden (rms_norm, q/k/v, RoPE, append, paged attention), wo, residual,
+// rms_norm, w_gate | w_up, SwiGLU, w_down, residual } -> final rms_norm of each request's last row ->
+// classifier -> greedy argmax (include/core/sampler.hpp:27-29: the first maximum).
+// Host code over the public C ABI of this library plus four elementwise kernels.  No CPU path.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "nvk_internal.h"
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return nvk::fail(e__ == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "%s failed: %s (%s:%d)", #expr,  \
+                             hipGetErrorString(e__), __FILE__, __LINE__);                                              \
+    } while (0)
+
+namespace {
+
+// x[r] = token_embedding_table[tokens[r]]  (model.hpp:153-154), float4 per thread
+__global__ void nvk_embed_kernel(float *__restrict__ x, const float *__restrict__ table, const int *__restrict__ tokens,
+                                 int dim, int vocab)
+{
+    const int     tok = min(max(tokens[blockIdx.x], 0), vocab - 1);
+    const float4 *src = reinterpret_cast<const float4 *>(table + (int64_t)tok * dim);
+    float4       *dst = reinterpret_cast<float4 *>(x + (int64_t)blockIdx.x * dim);
+    for (int i = threadIdx.x; i < dim / 4; i += blockDim.x)
+        dst[i] = src[i];
+}
+
+// x += y  (model.hpp:227-228, 238-239)
+__global__ void nvk_residual_kernel(float *__restrict__ x, const float *__restrict__ y, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4       a = reinterpret_cast<float4 *>(x)[i];
+        const float4 b = reinterpret_cast<const float4 *>(y)[i];
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        reinterpret_cast<float4 *>(x)[i] = a;
+    }
+}
+
+// hb = silu(gate) * up, silu(g) = g / (1 + expf(-g))  (Ops::swiglu, include/ops/activation.hpp:34-40)
+__global__ void nvk_swiglu_kernel(float *__restrict__ hb, const float *__restrict__ up, int64_t n)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g   = hb[i];
+        const float val = g / (1.0f + expf(-g));
+        hb[i]           = val * up[i];
+    }
+}
+
+// dst[i] = src[rows[i]]: each request's last row (the only one whose logits are wanted)
+__global__ void nvk_take_rows_kernel(float *__restrict__ dst, const float *__restrict__ src, const int *__restrict__ rows,
+                                     int dim)
+{
+    const float4 *s = reinterpret_cast<const float4 *>(src + (int64_t)rows[blockIdx.x] * dim);
+    float4       *d = reinterpret_cast<float4 *>(dst + (int64_t)blockIdx.x * dim);
+    for (int i = threadIdx.x; i < dim / 4; i += blockDim.x)
+        d[i] = s[i];
+}
+
+// next[r] = index of the first maximum of logits[r]  (Sampler, include/core/sampler.hpp:27-29: std::max_element)
+__global__ void __launch_bounds__(256) nvk_argmax_kernel(int *__restrict__ next, const float *__restrict__ logits, int vocab)
+{
+    __shared__ float s_v[256];
+    __shared__ int   s_i[256];
+    const float     *row = logits + (int64_t)blockIdx.x * vocab;
+    float            best = -INFINITY;
+    int              at   = 0x7fffffff;
+    for (int i = threadIdx.x; i < vocab; i += 256) {
+        const float v = row[i];
+        if (v > best || (v == best && i < at) || at == 0x7fffffff)
+            best = v, at = i;
+    }
+    s_v[threadIdx.x] = best, s_i[threadIdx.x] = at;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float v = s_v[threadIdx.x + o];
+            const int   i = s_i[threadIdx.x + o];
+            if (v > s_v[threadIdx.x] || (v == s_v[threadIdx.x] && i < s_i[threadIdx.x]))
+                s_v[threadIdx.x] = v, s_i[threadIdx.x] = i;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        next[blockIdx.x] = s_i[0] == 0x7fffffff ? 0 : s_i[0];
+}
+
+struct DeviceScope
+{
+    int previous = -1;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&previous) != hipSuccess)
+            previous = -1;
+        (void)hipSetDevice(device);
+    }
+    ~DeviceScope()
+    {
+        if (previous >= 0)
+            (void)hipSetDevice(previous);
+    }
+};
+
+struct LayerWeights
+{
+    const float *rms_att, *wq, *wk, *wv, *wo, *rms_ffn, *w_gate, *w_down, *w_up;
+};
+
+} // namespace
+
+struct nvk_model
+{
+    int  dim = 0, hidden_dim = 0, n_layers = 0, n_heads = 0, n_kv_heads = 0, vocab = 0, max_seq_len = 0, head_dim = 0;
+    bool shared = false;
+    int  device = 0, max_seqs = 0, max_rows = 0;
+    float rope_theta = 10000.0f, rms_eps = 1e-5f; // model.hpp:40, normalization.hpp:13
+
+    float                    *weights = nullptr; // one allocation, file order
+    const float              *tok_emb = nullptr, *rms_final = nullptr, *lm_head = nullptr;
+    std::vector<LayerWeights> layers;
+
+    nvk_pool          *pool  = nullptr;
+    nvk_block_manager *bm    = nullptr;
+    nvk_batch         *batch = nullptr;
+    hipStream_t        stream = nullptr; // the pool's
+
+    // activations for up to max_rows rows (grown on demand) and per-request outputs
+    float *x = nullptr, *xb = nullptr, *att = nullptr, *hb = nullptr, *hb2 = nullptr;
+    float *xl = nullptr, *logits = nullptr; // [max_seqs, dim], [max_seqs, vocab]
+    int   *tokens_dev = nullptr, *last_rows_dev = nullptr, *next_dev = nullptr;
+    int   *pinned = nullptr; // tokens | last rows | next tokens
+    size_t pinned_ints = 0;
+};
+
+namespace {
+
+void release(nvk_model *m)
+{
+    if (!m)
+        return;
+    DeviceScope scope(m->device);
+    (void)hipDeviceSynchronize();
+    if (m->batch)
+        (void)nvk_batch_destroy(m->batch);
+    if (m->pool)
+        (void)nvk_pool_destroy(m->pool);
+    if (m->bm)
+        nvk_bm_destroy(m->bm);
+    for (float *p : {m->weights, m->x, m->xb, m->att, m->hb, m->hb2, m->xl, m->logits})
+        if (p)
+            (void)hipFree(p);
+    for (int *p : {m->tokens_dev, m->last_rows_dev, m->next_dev})
+        if (p)
+            (void)hipFree(p);
+    if (m->pinned)
+        (void)hipHostFree(m->pinned);
+    delete m;
+}
+
+int reserve_rows(nvk_model *m, int rows)
+{
+    if (rows <= m->max_rows)
+        return NVK_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    for (float **p : {&m->x, &m->xb, &m->att, &m->hb, &m->hb2})
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    if (m->tokens_dev)
+        (void)hipFree(m->tokens_dev);
+    if (m->pinned)
+        (void)hipHostFree(m->pinned);
+    m->tokens_dev = nullptr, m->pinned = nullptr, m->max_rows = 0;
+    const size_t r = (size_t)std::max(rows, m->max_seqs);
+    HIP_TRY(hipMalloc((void **)&m->x, r * m->dim * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&m->xb, r * m->dim * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&m->att, r * (size_t)m->n_heads * m->head_dim * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&m->hb, r * m->hidden_dim * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&m->hb2, r * m->hidden_dim * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&m->tokens_dev, r * sizeof(int)));
+    m->pinned_ints = r + 2 * (size_t)m->max_seqs;
+    HIP_TRY(hipHostMalloc((void **)&m->pinned, m->pinned_ints * sizeof(int), hipHostMallocDefault));
+    m->max_rows = (int)r;
+    return NVK_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int nvk_model_load(const char *checkpoint_path, int block_size, int num_blocks, int max_seqs, int device,
+                   nvk_model **out_model)
+{
+    if (!out_model)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: out_model is null");
+    *out_model = nullptr;
+    if (!checkpoint_path || block_size <= 0 || num_blocks <= 0 || max_seqs <= 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: bad arguments");
+    FILE *f = fopen(checkpoint_path, "rb");
+    if (!f)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "Failed to open model file: %s", checkpoint_path); // model.hpp:123
+    int hdr[7];
+    if (fread(hdr, sizeof(int), 7, f) != 7) {
+        fclose(f);
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: %s is shorter than its header", checkpoint_path);
+    }
+    const int D = hdr[0], Hd = hdr[1], L = hdr[2], H = hdr[3], KV = hdr[4], V = hdr[5], S = hdr[6];
+    if (D <= 0 || Hd <= 0 || L <= 0 || H <= 0 || KV <= 0 || V <= 0 || S <= 0 || D % H != 0 || H % KV != 0) {
+        fclose(f);
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: implausible header (dim %d, hidden %d, layers %d, heads %d/%d, "
+                                              "vocab %d, max_seq_len %d)", D, Hd, L, H, KV, V, S);
+    }
+    const int hd = D / H; // model.hpp:129
+    const size_t QD = (size_t)H * hd, KD = (size_t)KV * hd;
+    if (D % 4 != 0 || Hd % 4 != 0 || QD % 4 != 0) {
+        fclose(f);
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: dim, hidden_dim and n_heads*head_dim must be multiples of 4");
+    }
+    // tensor sizes in file order (model.hpp:322-347)
+    const size_t sizes[11] = {(size_t)V * D, (size_t)L * D,      (size_t)L * QD * D, (size_t)L * KD * D,
+                              (size_t)L * KD * D, (size_t)L * D * QD, (size_t)L * D, (size_t)L * Hd * D,
+                              (size_t)L * D * Hd, (size_t)L * Hd * D, (size_t)D};
+    size_t body = 0;
+    for (size_t s : sizes)
+        body += s;
+    fseek(f, 0, SEEK_END);
+    const long long file_floats = ((long long)ftell(f) - 7 * (long long)sizeof(int)) / (long long)sizeof(float);
+    if (file_floats < (long long)body) {
+        fclose(f);
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: %s holds %lld floats, the header asks for %zu",
+                         checkpoint_path, file_floats, body);
+    }
+    const bool   has_head = file_floats - (long long)body >= (long long)V * D; // model.hpp:356
+    const size_t total    = body + (has_head ? (size_t)V * D : 0);
+    fseek(f, 7 * sizeof(int), SEEK_SET);
+
+    int rc = NVK_OK;
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+            fclose(f);
+            return nvk::fail(NVK_ERR_NO_DEVICE, "nvk_model_load: no HIP device visible (this library has no CPU path)");
+        }
+        if (device < 0 || device >= ndev) {
+            fclose(f);
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: device %d outside [0,%d)", device, ndev);
+        }
+    }
+    nvk_model *m = new (std::nothrow) nvk_model();
+    if (!m) {
+        fclose(f);
+        return nvk::fail(NVK_ERR_OOM, "nvk_model_load: host allocation failed");
+    }
+    m->dim = D, m->hidden_dim = Hd, m->n_layers = L, m->n_heads = H, m->n_kv_heads = KV, m->vocab = V, m->max_seq_len = S;
+    m->head_dim = hd, m->shared = !has_head, m->device = device, m->max_seqs = max_seqs;
+    DeviceScope scope(device);
+
+    // stream the file to the device in 64 MiB pieces through one pinned buffer
+    hipError_t e = hipMalloc((void **)&m->weights, total * sizeof(float));
+    float     *stage = nullptr;
+    const size_t piece = (size_t)16 << 20; // floats
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&stage, std::min(piece, total) * sizeof(float), hipHostMallocDefault);
+    for (size_t at = 0; e == hipSuccess && at < total; at += piece) {
+        const size_t n = std::min(piece, total - at);
+        if (fread(stage, sizeof(float), n, f) != n) {
+            rc = nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_load: short read in %s", checkpoint_path);
+            break;
+        }
+        e = hipMemcpy(m->weights + at, stage, n * sizeof(float), hipMemcpyHostToDevice);
+    }
+    fclose(f);
+    if (stage)
+        (void)hipHostFree(stage);
+    if (e != hipSuccess)
+        rc = nvk::fail(e == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "nvk_model_load: %s", hipGetErrorString(e));
+    if (rc != NVK_OK) {
+        release(m);
+        return rc;
+    }
+    const float *p[12];
+    size_t       at = 0;
+    for (int i = 0; i < 11; i++) {
+        p[i] = m->weights + at;
+        at += sizes[i];
+    }
+    p[11]        = has_head ? m->weights + at : p[0];
+    m->tok_emb   = p[0];
+    m->rms_final = p[10];
+    m->lm_head   = p[11];
+    m->layers.resize((size_t)L);
+    for (int l = 0; l < L; l++) {
+        LayerWeights &w = m->layers[(size_t)l];
+        w.rms_att = p[1] + (size_t)l * D, w.wq = p[2] + (size_t)l * QD * D, w.wk = p[3] + (size_t)l * KD * D;
+        w.wv = p[4] + (size_t)l * KD * D, w.wo = p[5] + (size_t)l * D * QD, w.rms_ffn = p[6] + (size_t)l * D;
+        w.w_gate = p[7] + (size_t)l * Hd * D, w.w_down = p[8] + (size_t)l * D * Hd, w.w_up = p[9] + (size_t)l * Hd * D;
+    }
+
+    // the paged KV pool, its allocator and the batch (initialize_paged_attention, model.hpp:249-277)
+    rc = nvk_pool_create(L, num_blocks, block_size, KV, hd, device, &m->pool);
+    if (rc == NVK_OK)
+        rc = nvk_bm_create(num_blocks, block_size, &m->bm);
+    if (rc == NVK_OK)
+        rc = nvk_batch_create(m->pool, m->bm, max_seqs, (S + block_size - 1) / block_size, &m->batch);
+    void *st = nullptr;
+    if (rc == NVK_OK)
+        rc = nvk_pool_stream(m->pool, &st);
+    m->stream = (hipStream_t)st;
+    if (rc == NVK_OK) {
+        e = hipMalloc((void **)&m->xl, (size_t)max_seqs * D * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&m->logits, (size_t)max_seqs * V * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&m->last_rows_dev, (size_t)max_seqs * sizeof(int));
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&m->next_dev, (size_t)max_seqs * sizeof(int));
+        if (e != hipSuccess)
+            rc = nvk::fail(e == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "nvk_model_load: %s", hipGetErrorString(e));
+    }
+    if (rc == NVK_OK)
+        rc = reserve_rows(m, max_seqs);
+    if (rc != NVK_OK) {
+        release(m);
+        return rc;
+    }
+    *out_model = m;
+    return NVK_OK;
+}
+
+int nvk_model_destroy(nvk_model *model)
+{
+    release(model);
+    return NVK_OK;
+}
+
+int nvk_model_config(const nvk_model *m, int *out8)
+{
+    if (!m || !out8)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_config: null argument");
+    out8[0] = m->dim, out8[1] = m->hidden_dim, out8[2] = m->n_layers, out8[3] = m->n_heads, out8[4] = m->n_kv_heads;
+    out8[5] = m->vocab, out8[6] = m->max_seq_len, out8[7] = m->shared ? 1 : 0;
+    return NVK_OK;
+}
+
+int nvk_model_add_request(nvk_model *m, int request_id)
+{
+    if (!m)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_add_request: null model");
+    return nvk_batch_add_request(m->batch, request_id);
+}
+
+int nvk_model_finish_request(nvk_model *m, int request_id)
+{
+    if (!m)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_finish_request: null model");
+    return nvk_batch_finish_request(m->batch, request_id);
+}
+
+int nvk_model_request_len(const nvk_model *m, int request_id)
+{
+    if (!m)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_request_len: null model");
+    return nvk_batch_request_len(m->batch, request_id);
+}
+
+int nvk_model_free_blocks(const nvk_model *m) { return m ? nvk_bm_num_free_blocks(m->bm) : 0; }
+
+int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk_lens, const int *tokens, int n,
+                          int *next_tokens, float *logits)
+{
+    if (!m || n < 0 || (n > 0 && (!request_ids || !chunk_lens || !tokens)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: bad arguments");
+    if (n == 0)
+        return NVK_OK;
+    if (n > m->max_seqs)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: %d requests, %d slots", n, m->max_seqs);
+    long long rows = 0;
+    for (int i = 0; i < n; i++) {
+        if (chunk_lens[i] < 1)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: request %d brings %d tokens", request_ids[i],
+                             chunk_lens[i]);
+        const int len = nvk_batch_request_len(m->batch, request_ids[i]);
+        if (len < 0)
+            return len;
+        if ((long long)len + chunk_lens[i] > m->max_seq_len)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: request %d would reach %lld tokens, max_seq_len is %d",
+                             request_ids[i], (long long)len + chunk_lens[i], m->max_seq_len);
+        rows += chunk_lens[i];
+    }
+    if (rows > 0x3fffffffLL)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: %lld rows in one step", rows);
+    DeviceScope scope(m->device);
+    int         rc = reserve_rows(m, (int)rows);
+    if (rc != NVK_OK)
+        return rc;
+    const int   R = (int)rows, D = m->dim, Hd = m->hidden_dim, V = m->vocab, QD = m->n_heads * m->head_dim;
+    hipStream_t st = m->stream;
+
+    // the step's rows follow the batch's order: decode (one-token) requests must come first
+    int *h_tok = m->pinned, *h_last = m->pinned + m->max_rows, *h_next = h_last + m->max_seqs;
+    HIP_TRY(hipStreamSynchronize(st)); // the pinned buffer is ours
+    int r = 0;
+    for (int i = 0; i < n; i++) {
+        r += chunk_lens[i];
+        h_last[i] = r - 1;
+    }
+    std::memcpy(h_tok, tokens, (size_t)R * sizeof(int));
+    rc = nvk_batch_begin_step_chunks(m->batch, request_ids, chunk_lens, n, m->n_heads, (void *)st);
+    if (rc != NVK_OK)
+        return rc;
+    // a failure inside the step: no request advances; K/V rows it already wrote are overwritten by the next step
+    auto fail_step = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        (void)nvk_batch_abort_step(m->batch);
+        return code;
+    };
+    if (hipMemcpyAsync(m->tokens_dev, h_tok, (size_t)R * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess
+        || hipMemcpyAsync(m->last_rows_dev, h_last, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail_step(nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: staging the tokens failed"));
+    hipLaunchKernelGGL(nvk_embed_kernel, dim3((unsigned)R), dim3(64), 0, st, m->x, m->tok_emb, m->tokens_dev, D, V);
+    const unsigned ew_blocks = 1024;
+    for (int l = 0; l < m->n_layers && rc == NVK_OK; l++) {
+        const LayerWeights &w = m->layers[(size_t)l];
+        rc = nvk_batch_layer_hidden(m->batch, l, m->x, D, w.rms_att, w.wq, w.wk, w.wv, m->rms_eps, m->att, m->rope_theta,
+                                    (void *)st); // model.hpp:161-221
+        if (rc == NVK_OK)
+            rc = nvk_batch_matmul_device(m->xb, m->att, w.wo, R, QD, D, m->device, (void *)st); // :224
+        if (rc != NVK_OK)
+            break;
+        hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4); // :227
+        rc = nvk_batch_rms_norm_device(m->xb, m->x, w.rms_ffn, R, D, m->rms_eps, m->device, (void *)st);             // :231
+        if (rc == NVK_OK)
+            rc = nvk_batch_matmul2_device(m->hb, m->hb2, m->xb, w.w_gate, w.w_up, R, D, Hd, Hd, m->device, (void *)st); // :232-233
+        if (rc != NVK_OK)
+            break;
+        hipLaunchKernelGGL(nvk_swiglu_kernel, dim3(ew_blocks), dim3(256), 0, st, m->hb, m->hb2, (int64_t)R * Hd);   // :234
+        rc = nvk_batch_matmul_device(m->xb, m->hb, w.w_down, R, Hd, D, m->device, (void *)st);                      // :235
+        if (rc != NVK_OK)
+            break;
+        hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4); // :238
+    }
+    if (rc != NVK_OK)
+        return fail_step(rc);
+    // final norm + classifier for each request's last row only (model.hpp:243-246), then the greedy sampler
+    hipLaunchKernelGGL(nvk_take_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, m->xl, m->x, m->last_rows_dev, D);
+    rc = nvk_batch_rms_norm_device(m->xl, m->xl, m->rms_final, n, D, m->rms_eps, m->device, (void *)st);
+    if (rc == NVK_OK)
+        rc = nvk_batch_matmul_device(m->logits, m->xl, m->lm_head, n, D, V, m->device, (void *)st);
+    if (rc != NVK_OK)
+        return fail_step(rc);
+    hipLaunchKernelGGL(nvk_argmax_kernel, dim3((unsigned)n), dim3(256), 0, st, m->next_dev, m->logits, V);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h_next, m->next_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && logits)
+        e = hipMemcpyAsync(logits, m->logits, (size_t)n * V * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+        return fail_step(nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: %s", hipGetErrorString(e)));
+    rc = nvk_batch_end_step(m->batch);
+    if (rc != NVK_OK)
+        return rc;
+    if (next_tokens)
+        std::memcpy(next_tokens, h_next, (size_t)n * sizeof(int));
+    return NVK_OK;
+}
+
+int nvk_model_step(nvk_model *m, const int *request_ids, const int *tokens, int n, int *next_tokens, float *logits)
+{
+    if (!m || n < 0 || n > 1 << 20)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step: bad arguments");
+    std::vector<int> ones((size_t)n, 1);
+    return nvk_model_step_chunks(m, request_ids, ones.data(), tokens, n, next_tokens, logits);
+}
+
+int nvk_model_forward(nvk_model *m, int token, int pos, float *logits)
+{
+    if (!m)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_forward: null model");
+    // LlamaModel::forward(token, pos): one sequence, request 0, created on first use; pos is its length
+    int len = nvk_batch_request_len(m->batch, 0);
+    if (len < 0) {
+        int rc = nvk_batch_add_request(m->batch, 0);
+        if (rc != NVK_OK)
+            return rc;
+        len = 0;
+    }
+    if (pos != len)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_forward: pos %d, the sequence holds %d tokens", pos, len);
+    const int id = 0, one = 1;
+    return nvk_model_step_chunks(m, &id, &one, &token, 1, nullptr, logits);
+}
+
+} // extern "C"

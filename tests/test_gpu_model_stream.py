@@ -99,3 +99,89 @@ def test_greedy_streams_with_the_forward_pass_on_the_gpu(spec, golden_dir):
         assert stream == gold[n + "/greedy_stream"].tolist()
     finally:
         m.close()
+
+
+# ---- the same through the device-resident model (nvk_model_*): nothing but token ids and logits cross PCIe ----
+@pytest.fixture(scope="module")
+def checkpoints(tmp_path_factory):
+    from golden_defs import write_checkpoint
+    d = tmp_path_factory.mktemp("ckpt")
+    out = {}
+    for spec in TINY_MODELS:
+        path = str(d / (spec["name"] + ".bin"))
+        write_checkpoint(path, spec)
+        out[spec["name"]] = path
+    return out
+
+
+@pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])
+def test_device_model_forward_matches_the_reference_stream(spec, checkpoints, golden_dir):
+    import nano_vllm_amd as nv
+
+    gold = np.load(os.path.join(golden_dir, "tiny_llama_stream.npz"))
+    n = spec["name"]
+    with nv.LlamaModel(checkpoints[n], spec["block_size"], spec["num_blocks"]) as m:
+        assert (m.dim, m.hidden_dim, m.n_layers, m.n_heads, m.n_kv_heads, m.vocab_size, m.max_seq_len) == \
+            tuple(spec[k] for k in ("dim", "hidden_dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size", "max_seq_len"))
+        assert m.weights_shared == spec["shared"]  # the shared-classifier rule, model.hpp:349-364
+        for pos, tok in enumerate(spec["forced_tokens"]):
+            logits = m.forward(int(tok), pos)
+            want = gold[n + "/tf_logits"][pos]
+            assert np.all(np.abs(logits - want) <= 2e-3 + 1e-4 * np.abs(want)), (pos, float(np.abs(logits - want).max()))
+            assert int(np.argmax(logits)) == int(gold[n + "/tf_argmax"][pos]), pos
+        with pytest.raises(nv.NvkError):
+            m.forward(0, 3)  # pos must be the sequence's length
+    with nv.LlamaModel(checkpoints[n], spec["block_size"], spec["num_blocks"]) as m:
+        prompt = spec["prompt_tokens"]
+        m.add_request(7)
+        nxt, _ = m.step_chunks([7], [prompt])  # the whole prompt as one prefill chunk
+        stream = [int(nxt[0])]
+        for _ in range(spec["gen_steps"] - 1):
+            nxt, _ = m.step([7], [stream[-1]])
+            stream.append(int(nxt[0]))
+        assert stream == gold[n + "/greedy_stream"].tolist()
+        m.finish_request(7)
+        assert m.free_blocks == spec["num_blocks"]
+
+
+def test_device_model_batched_requests_equal_their_single_runs(checkpoints):
+    """Continuous batching at the model level: requests with different prompts join at different steps (prompt as one
+    chunk beside the others' decode tokens); every request's greedy stream equals the stream it produces alone."""
+    import nano_vllm_amd as nv
+
+    spec = TINY_MODELS[0]
+    rng = np.random.default_rng(3)
+    prompts = {r: [1] + rng.integers(3, spec["vocab_size"], size=k).tolist() for r, k in ((1, 4), (2, 11), (3, 1), (4, 23))}
+    join = {1: 0, 2: 0, 3: 3, 4: 5}
+    gen = 20
+    alone = {}
+    for r, prompt in prompts.items():
+        with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"]) as m:
+            m.add_request(0)
+            nxt, _ = m.step_chunks([0], [prompt])
+            s = [int(nxt[0])]
+            while len(s) < gen:
+                nxt, _ = m.step([0], [s[-1]])
+                s.append(int(nxt[0]))
+            alone[r] = s
+    with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"], max_seqs=4) as m:
+        streams, running = {}, []
+        step = 0
+        while step < 60 and (running or any(j >= step for j in join.values())):
+            decode = [r for r in running if len(streams[r]) < gen]
+            fresh = [r for r, j in join.items() if j == step]
+            for r in fresh:
+                m.add_request(r)
+                streams[r] = []
+            ids = decode + fresh
+            if ids:
+                nxt, _ = m.step_chunks(ids, [[streams[r][-1]] for r in decode] + [prompts[r] for r in fresh])
+                for r, t in zip(ids, nxt.tolist()):
+                    streams[r].append(int(t))
+            running = [r for r in decode + fresh if len(streams[r]) < gen]
+            for r in decode + fresh:
+                if len(streams[r]) >= gen:
+                    m.finish_request(r)
+            step += 1
+        assert streams == alone
+        assert m.free_blocks == spec["num_blocks"]
