@@ -18,8 +18,8 @@ all: lib oracle ref
 
 lib: $(LIB)
 
-$(LIB): $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_kernels.hip.h $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_internal.h include/nvk_paged_attn.h
-	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_block_manager.cpp
+$(LIB): $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_kernels.hip.h $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp $(CSRC)/nvk_internal.h include/nvk_paged_attn.h
+	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp
 
 # device assembly + register/occupancy report for the kernels (not needed to run)
 asm:

@@ -348,6 +348,21 @@ int nvk_batch_abort_step(nvk_batch *batch);
 /* out2 = {steps that uploaded whole tables, steps that only patched new entries} */
 int nvk_batch_stats(const nvk_batch *batch, long long *out2);
 
+/* ------------------------------------------------------------- the tokenizer --
+ * tokenizer.bin and the reference's BPE, host-only, same ids bit for bit.
+ * ref: class Tokenizer, include/core/tokenizer.hpp -- load :31-61, decode :63-75, encode :77-131 (BOS = 1,
+ * dummy-prefix " ", one lookup per byte with unknown bytes dropped, best-score pair merges, EOS = 2). */
+typedef struct nvk_tokenizer nvk_tokenizer;
+int  nvk_tokenizer_load(const char *path, int vocab_size, nvk_tokenizer **out_tokenizer);
+void nvk_tokenizer_destroy(nvk_tokenizer *tokenizer);
+int  nvk_tokenizer_vocab_size(const nvk_tokenizer *tokenizer);
+int  nvk_tokenizer_max_token_length(const nvk_tokenizer *tokenizer);
+/* Bytes of the piece (NUL-terminated copy of at most cap-1 of them in out); "" for ids outside the vocabulary. */
+int  nvk_tokenizer_decode(const nvk_tokenizer *tokenizer, int token, char *out, int cap);
+/* Number of ids of the encoding (at most cap written).  text_len < 0: strlen(text). */
+int  nvk_tokenizer_encode(const nvk_tokenizer *tokenizer, const char *text, int text_len, int bos, int eos, int *ids,
+                          int cap);
+
 /* ------------------------------------------------------ the model on the device --
  * SURVEY.md 8f row f4 (checkpoint format) and the caller of the whole path: a llama2.c checkpoint resident in HBM
  * and LlamaModel::forward (include/core/model.hpp:150-247) as batched steps, nothing but token ids and results

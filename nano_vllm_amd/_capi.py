@@ -117,6 +117,12 @@ SIGNATURES = {
     "nvk_batch_begin_step_chunks": (C.c_int, [_vp, _i, _i, C.c_int, C.c_int, _vp]),
     "nvk_batch_step_rows": (C.c_int, [_vp]),
     "nvk_batch_abort_step": (C.c_int, [_vp]),
+    "nvk_tokenizer_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "nvk_tokenizer_destroy": (None, [_vp]),
+    "nvk_tokenizer_vocab_size": (C.c_int, [_vp]),
+    "nvk_tokenizer_max_token_length": (C.c_int, [_vp]),
+    "nvk_tokenizer_decode": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int]),
+    "nvk_tokenizer_encode": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_int, _i, C.c_int]),
     "nvk_model_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "nvk_model_destroy": (C.c_int, [_vp]),
     "nvk_model_config": (C.c_int, [_vp, _i]),

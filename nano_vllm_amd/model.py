@@ -34,7 +34,7 @@ class LlamaModel:
         return cls(path, **kw)
 
     def close(self) -> None:
-        if self._h:
+        if getattr(self, "_h", None):
             _capi.lib.nvk_model_destroy(self._h)
             self._h = C.c_void_p()
 

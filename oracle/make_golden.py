@@ -11,6 +11,7 @@ outputs; the fixtures are data only (no reference source in any form).
   F2  tests/golden/attention_cases.npz         single-sequence paged_attention outputs
   F3  (same file) standard_attention outputs on the same rows (paged == contiguous)
   F6  tests/golden/prefill_cases.npz           chunked_attention outputs (experimental/chunked_prefill)
+  F8  tests/golden/tokenizer_cases.json        Tokenizer::encode / decode over a synthetic tokenizer.bin
   F7  tests/golden/qkv_cases.npz               Ops::rms_norm + Ops::matmul (q/k/v projections), = the BatchOps forms
   F4  tests/golden/tiny_llama_stream.npz       synthetic llama2.c checkpoint: token stream,
                                                logits, attention outputs, F5 block tables
@@ -32,7 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as ol  # noqa: E402
-from golden_defs import (ATTENTION_CASES, PREFILL_CASES, QKV_CASES, TINY_MODELS, qkv_case_inputs, BmCLib, attention_case_inputs,  # noqa: E402
+from golden_defs import (ATTENTION_CASES, PREFILL_CASES, QKV_CASES, TINY_MODELS, TOKENIZER_TEXTS, qkv_case_inputs, write_tokenizer, BmCLib, attention_case_inputs,  # noqa: E402
                          bm_trace_script, prefill_case_inputs, replay, write_checkpoint)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -100,6 +101,23 @@ def main():
             store[case["name"] + "/" + key] = out
     np.savez_compressed(os.path.join(GOLD, "qkv_cases.npz"), **store)
     print(f"F7: {len(QKV_CASES)} rms_norm + qkv projection cases")
+
+    # ---- F8: tokenizer.bin + Tokenizer::encode / decode (tokenizer.hpp) ----------------
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "tokenizer.bin")
+        write_tokenizer(path, 512)
+        tok = ol.REF.ref_tokenizer_create(path.encode(), 512)
+        assert tok
+        f8 = {"vocab_size": 512,
+              "encode": [{"text_hex": t.hex(), "bos": bos, "eos": eos, "ids": ol.ref_tokenizer_encode(tok, t, bos, eos)}
+                         for t in TOKENIZER_TEXTS for bos, eos in ((True, False), (True, True))
+                         ] + [{"text_hex": t.hex(), "bos": False, "eos": False, "ids": ol.ref_tokenizer_encode(tok, t, False, False)}
+                              for t in TOKENIZER_TEXTS if len(t) > 0],
+              "decode_hex": [ol.ref_tokenizer_decode(tok, i).hex() for i in range(-1, 513)]}
+        ol.REF.ref_tokenizer_destroy(tok)
+    with open(os.path.join(GOLD, "tokenizer_cases.json"), "w") as fh:
+        json.dump(f8, fh)
+    print(f"F8: {len(f8['encode'])} encodings, {len(f8['decode_hex'])} decoded pieces")
 
     # ---- F4 / F5 ---------------------------------------------------------------
     store = {}

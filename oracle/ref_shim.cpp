@@ -17,6 +17,7 @@
 //   Sampler (greedy branch)         include/core/sampler.hpp:24-29
 //   Ops::apply_rope                 include/ops/positional.hpp:13-39
 //   LlamaModelChunked::chunked_attention  experimental/chunked_prefill/model_chunked.hpp:167-224
+//   Tokenizer                       include/core/tokenizer.hpp:15-149
 //   Ops::rms_norm, Ops::matmul      include/ops/normalization.hpp:13-23, include/ops/linear.hpp:12-22
 //   BatchOps::batch_rms_norm, batch_matmul  experimental/chunked_prefill/batch_ops.hpp:58-76, :8-23
 
@@ -35,6 +36,7 @@
 #include "core/attention.hpp"
 #include "core/model.hpp"
 #include "core/sampler.hpp"
+#include "core/tokenizer.hpp"
 #include "scheduler/block_manager.hpp"
 
 // LlamaModelChunked::chunked_attention is a private member (model_chunked.hpp:166-167); the shim
@@ -152,6 +154,41 @@ void ref_batch_rms_norm(float *out, const float *in, const float *weight, int ba
 void ref_batch_matmul(float *out, const float *in, const float *weight, int batch_size, int in_dim, int out_dim)
 {
     BatchOps::batch_matmul(out, in, weight, batch_size, in_dim, out_dim);
+}
+
+// ---------------------------------------------------------------- Tokenizer
+// class Tokenizer, include/core/tokenizer.hpp (reached through core/runner-free includes below)
+void *ref_tokenizer_create(const char *path, int vocab_size)
+{
+    Quiet hush;
+    try {
+        return new Tokenizer(path, vocab_size);
+    }
+    catch (const std::exception &) {
+        return nullptr;
+    }
+}
+
+void ref_tokenizer_destroy(void *t) { delete static_cast<Tokenizer *>(t); }
+
+int ref_tokenizer_encode(void *t, const char *text, int text_len, int bos, int eos, int *ids, int cap)
+{
+    std::vector<int> v = static_cast<Tokenizer *>(t)->encode(std::string(text, (size_t)text_len), bos != 0, eos != 0);
+    for (int i = 0; i < (int)v.size() && i < cap; i++)
+        ids[i] = v[(size_t)i];
+    return (int)v.size();
+}
+
+int ref_tokenizer_decode(void *t, int token, char *out, int cap)
+{
+    const std::string piece = static_cast<Tokenizer *>(t)->decode(token);
+    const int         n     = (int)piece.size();
+    if (cap > 0) {
+        const int c = std::min(n, cap - 1);
+        std::memcpy(out, piece.data(), (size_t)c);
+        out[c] = '\0';
+    }
+    return n;
 }
 
 // ------------------------------------------------------------- BlockManager

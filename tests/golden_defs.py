@@ -312,3 +312,47 @@ def write_checkpoint(path, spec):
                              spec["n_kv_heads"], spec["vocab_size"], spec["max_seq_len"]))
         for _, w in checkpoint_tensors(spec):
             fh.write(w.tobytes())
+
+
+# ---- F8: a synthetic tokenizer.bin (reference format, tokenizer.hpp:31-61) and texts to encode ----------------
+def tokenizer_spec(vocab_size=512):
+    """(pieces, scores, max_token_length): ids 0-2 <unk> <s> </s>, 3-258 the byte pieces <0x00>..<0xFF>, then single
+    printable characters, then multi-character pieces (merges) with descending scores -- the shape of llama2.c's
+    tokenizer, small.  Deterministic; no duplicates."""
+    pieces = [b"<unk>", b"<s>", b"</s>"] + [b"<0x%02X>" % i for i in range(256)]
+    singles = [bytes([c]) for c in b" etaoinshrdlucmfwypvbgkqjxzETAOINSHRDLUCMFWYPVBGKQJXZ0123456789.,!?'\"-:;()\n"]
+    pieces += singles
+    scores = [0.0] * len(pieces)
+    merges = [b" t", b"he", b" a", b"in", b" the", b"er", b" s", b"on", b"re", b" w", b"at", b"nd", b"en", b" o", b"ou",
+              b"ing", b" c", b"es", b"or", b" b", b"it", b"an", b" and", b"ll", b" h", b"is", b" f", b"ed", b" to", b"ar",
+              b" m", b" p", b"le", b" d", b"as", b"om", b" in", b"st", b" l", b"ow", b" you", b"ve", b"ot", b" how", b"ay",
+              b"hel", b"hell", b"hello", b" hello", b" are", b"wor", b"world", b" world", b"?!", b"...", b" on", b" once",
+              b" upon", b"time", b" time", b" was", b" there", b"ce", b"up", b"th", b" th", b"ere", b" is", b" it"]
+    seen = set(pieces)
+    for k, mrg in enumerate(merges):
+        if len(pieces) >= vocab_size:
+            break
+        if mrg not in seen:
+            pieces.append(mrg)
+            seen.add(mrg)
+            scores.append(-1.0 - 0.5 * k)
+    k = 0
+    while len(pieces) < vocab_size:  # filler pieces that never match ASCII text
+        pieces.append(b"\xf0\x9f" + bytes([0x80 + k // 64, 0x80 + k % 64]))
+        scores.append(-1000.0 - k)
+        k += 1
+    return pieces[:vocab_size], scores[:vocab_size], max(len(p) for p in pieces[:vocab_size])
+
+
+def write_tokenizer(path, vocab_size=512):
+    pieces, scores, max_len = tokenizer_spec(vocab_size)
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("i", max_len))
+        for piece, score in zip(pieces, scores):
+            fh.write(struct.pack("fi", score, len(piece)))
+            fh.write(piece)
+
+
+TOKENIZER_TEXTS = [b"", b"hello world", b"Hello, how are you?", b"the theory of the thing", b"once upon a time there was",
+                   b"  two  spaces", b"caf\xc3\xa9 \xe2\x82\xac5", b"a", b" ", b"?!...?!", b"tttttt", b"in the inn, an ant and a hen",
+                   b"line one\nline two", b"x" * 40, b"hellohellohello", b"0123456789"]

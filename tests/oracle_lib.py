@@ -114,6 +114,15 @@ def _load_ref(path):
         if hasattr(lib, name):
             getattr(lib, name).restype = None
             getattr(lib, name).argtypes = [_vp, _vp, _vp, _i, _i, _i]
+    if hasattr(lib, "ref_tokenizer_create"):
+        lib.ref_tokenizer_create.restype = _vp
+        lib.ref_tokenizer_create.argtypes = [C.c_char_p, _i]
+        lib.ref_tokenizer_destroy.restype = None
+        lib.ref_tokenizer_destroy.argtypes = [_vp]
+        lib.ref_tokenizer_encode.restype = _i
+        lib.ref_tokenizer_encode.argtypes = [_vp, C.c_char_p, _i, _i, _i, _vp, _i]
+        lib.ref_tokenizer_decode.restype = _i
+        lib.ref_tokenizer_decode.argtypes = [_vp, _i, C.c_char_p, _i]
     lib.ref_bm_create.restype = _vp
     lib.ref_bm_create.argtypes = [_i, _i]
     lib.ref_bm_destroy.restype = None
@@ -292,3 +301,17 @@ def batch_matmul(fn, x, weight):
     out = np.empty((x.shape[0], w.shape[0]), np.float32)
     fn(_p(out), _p(x), _p(w), x.shape[0], x.shape[1], w.shape[0])
     return out
+
+
+def ref_tokenizer_encode(tok, text: bytes, bos=True, eos=False):
+    """Token ids of the reference's Tokenizer::encode (tok = REF.ref_tokenizer_create(...))."""
+    cap = len(text) + 8
+    ids = (C.c_int * cap)()
+    n = REF.ref_tokenizer_encode(tok, text, len(text), int(bos), int(eos), ids, cap)
+    return list(ids[:n])
+
+
+def ref_tokenizer_decode(tok, token: int) -> bytes:
+    buf = C.create_string_buffer(256)
+    n = REF.ref_tokenizer_decode(tok, int(token), buf, 256)
+    return buf.raw[:n]
