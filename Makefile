@@ -2,6 +2,7 @@
 # snapshot to the GPU box (they are git-ignored, not gpurun-ignored).
 #
 #   make lib      libnvk_paged_attn.so: HIP kernels + C ABI, gfx950 only
+#   make cli      nano_vllm_amd/nvk_run: the reference's command line over the library
 #   make oracle   the CPU checker (oracle/, test infrastructure)
 #   make ref      the reference's own headers behind a shim (only where /root/reference exists)
 #   make all      all of the above
@@ -13,13 +14,19 @@ LIB     := nano_vllm_amd/libnvk_paged_attn.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -I$(CSRC) \
             -Wall -Wno-unused-function -fno-gpu-rdc
 
-.PHONY: all lib oracle ref clean asm
-all: lib oracle ref
+.PHONY: all lib cli oracle ref clean asm
+all: lib cli oracle ref
 
 lib: $(LIB)
 
 $(LIB): $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_kernels.hip.h $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp $(CSRC)/nvk_internal.h include/nvk_paged_attn.h
 	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp
+
+# the reference's command line over the library (tools/nvk_run.cpp): host-only C++ over the C ABI
+CLI := nano_vllm_amd/nvk_run
+cli: $(CLI)
+$(CLI): tools/nvk_run.cpp include/nvk_paged_attn.h $(LIB)
+	g++ -std=c++17 -O2 -Wall -Iinclude -o $@ tools/nvk_run.cpp -Lnano_vllm_amd -lnvk_paged_attn -Wl,-rpath,'$$ORIGIN'
 
 # device assembly + register/occupancy report for the kernels (not needed to run)
 asm:
@@ -34,6 +41,6 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(CLI)
 	rm -rf build
 	$(MAKE) -C oracle clean
