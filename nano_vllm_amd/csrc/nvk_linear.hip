@@ -41,6 +41,12 @@
 #ifndef NVK_GEMM_FORCE_TILE
 #define NVK_GEMM_FORCE_TILE 0 // tuning: 128 or 64 pins the tiled kernel's tile, 0 = by workgroup count
 #endif
+#ifndef NVK_GEMV_COLS
+#define NVK_GEMV_COLS 16 // weight rows (output columns) per GEMV workgroup: 8 or 16
+#endif
+#ifndef NVK_GEMV_DEPTH
+#define NVK_GEMV_DEPTH 2 // steps of weight loads a GEMV wave keeps in flight
+#endif
 #ifndef NVK_GEMV_MAX_ROWS
 #define NVK_GEMV_MAX_ROWS 2 // up to here the vector-ALU GEMV kernel (measured: from 3 rows on its registers allow one
                             // workgroup per CU and the MFMA kernel is as fast); at most 4, 0 switches it off
@@ -444,7 +450,8 @@ template <int T> __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_s
 // weight row -> the eight waves meet in LDS.  An output's summation order depends on k only.
 constexpr int kGemvWaves = 8, kGemvBK = 64;
 
-template <int M, int kGemvCols> __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
+template <int M, int kGemvCols, int DEPTH>
+__global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
 {
     __shared__ float s_red[kGemvWaves][M][kGemvCols];
     const int       nt = blockIdx.x;
@@ -462,15 +469,19 @@ template <int M, int kGemvCols> __global__ void __launch_bounds__(64 * kGemvWave
     for (int m = 0; m < M; m++)
         xoff[m] = min(m, p.m - 1) * p.lda + lc;
 
-    float4 rw0[R], rw1[R], rx0[M], rx1[M];
-    auto   fetch = [&](float4(&w)[R], float4(&x)[M], int k0) {
+    struct Step
+    {
+        float4 w[R], x[M];
+    };
+    Step ring[DEPTH]; // DEPTH steps of loads in flight (indices are compile-time after unrolling)
+    auto fetch = [&](Step &t, int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
         for (int i = 0; i < R; i++)
-            w[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            t.w[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int m = 0; m < M; m++)
-            x[m] = inside ? *reinterpret_cast<const float4 *>(p.a + xoff[m] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            t.x[m] = inside ? *reinterpret_cast<const float4 *>(p.a + xoff[m] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float acc[M][R];
 #pragma unroll
@@ -478,15 +489,15 @@ template <int M, int kGemvCols> __global__ void __launch_bounds__(64 * kGemvWave
 #pragma unroll
         for (int i = 0; i < R; i++)
             acc[m][i] = 0.f;
-    auto consume = [&](const float4(&w)[R], const float4(&x)[M]) {
+    auto consume = [&](const Step &t) {
 #pragma unroll
         for (int m = 0; m < M; m++)
 #pragma unroll
             for (int i = 0; i < R; i++) {
-                acc[m][i] = fmaf(w[i].x, x[m].x, acc[m][i]);
-                acc[m][i] = fmaf(w[i].y, x[m].y, acc[m][i]);
-                acc[m][i] = fmaf(w[i].z, x[m].z, acc[m][i]);
-                acc[m][i] = fmaf(w[i].w, x[m].w, acc[m][i]);
+                acc[m][i] = fmaf(t.w[i].x, t.x[m].x, acc[m][i]);
+                acc[m][i] = fmaf(t.w[i].y, t.x[m].y, acc[m][i]);
+                acc[m][i] = fmaf(t.w[i].z, t.x[m].z, acc[m][i]);
+                acc[m][i] = fmaf(t.w[i].w, t.x[m].w, acc[m][i]);
             }
     };
 
@@ -494,19 +505,18 @@ template <int M, int kGemvCols> __global__ void __launch_bounds__(64 * kGemvWave
     const int steps = nk > wave ? (nk - wave + kGemvWaves - 1) / kGemvWaves : 0;
     const int rot   = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
     auto      k_of  = [&](int s) { return ((wave + s * kGemvWaves + rot) % nk) * kGemvBK; };
-    if (steps > 0)
-        fetch(rw0, rx0, k_of(0));
-    if (steps > 1)
-        fetch(rw1, rx1, k_of(1));
-    for (int s = 0; s < steps; s += 2) {
-        consume(rw0, rx0);
-        if (s + 2 < steps)
-            fetch(rw0, rx0, k_of(s + 2));
-        if (s + 1 < steps) {
-            consume(rw1, rx1);
-            if (s + 3 < steps)
-                fetch(rw1, rx1, k_of(s + 3));
-        }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < steps)
+            fetch(ring[d], k_of(d));
+    for (int s = 0; s < steps; s += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (s + d < steps) {
+                consume(ring[d]);
+                if (s + d + DEPTH < steps)
+                    fetch(ring[d], k_of(s + d + DEPTH));
+            }
     }
 
 #pragma unroll
@@ -596,7 +606,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             bm = bn = 64;
     }
     else
-        bn = gemv ? (batch <= 2 ? 16 : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
+        bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
     long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
@@ -615,12 +625,12 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         p.m_tiles = 1;
         const dim3 grid((unsigned)tiles), block(64 * nvk::kGemvWaves);
         if (batch == 1)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, 16>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
         else if (batch == 2)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, 16>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
 #if NVK_GEMV_MAX_ROWS > 2
         else
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<4, 32>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<4, 32, 2>), grid, block, 0, st, p);
 #endif
     }
     else if (skinny) {

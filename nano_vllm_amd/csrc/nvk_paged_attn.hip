@@ -25,6 +25,9 @@
 #ifndef NVK_MAX_QPK
 #define NVK_MAX_QPK 8 // q-heads one wave carries at most (register budget: q and the accumulators grow with it)
 #endif
+#ifndef NVK_AUTO_MIN_CHUNK
+#define NVK_AUTO_MIN_CHUNK 128 // shortest chunk NVK_DECODE_AUTO picks (a multiple of every kernel step: 4..16 tokens)
+#endif
 #ifndef NVK_AUTO_MAX_CHUNK
 #define NVK_AUTO_MAX_CHUNK 2048 // longest chunk NVK_DECODE_AUTO picks
 #endif
@@ -259,8 +262,9 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
         // batch tolerates chunks up to 2048 tokens; 128 keeps the prologue/epilogue share small.
         const long long wg_per_chunk = std::max<long long>(1, (long long)plan->kv_groups * (kv_mul / plan->qpk));
         const long long tokens_upper = (long long)num_seqs * ctx_cap * wg_per_chunk;
-        chunk = round_up((int)std::min<long long>(1 << 20, (tokens_upper + pool->num_cus - 1) / pool->num_cus), 128);
-        chunk = std::max<long long>(128, std::min<long long>(chunk, NVK_AUTO_MAX_CHUNK));
+        chunk = round_up((int)std::min<long long>(1 << 20, (tokens_upper + pool->num_cus - 1) / pool->num_cus),
+                         NVK_AUTO_MIN_CHUNK);
+        chunk = std::max<long long>(NVK_AUTO_MIN_CHUNK, std::min<long long>(chunk, NVK_AUTO_MAX_CHUNK));
     }
     chunk = std::min<long long>(chunk, ctx_cap);
     chunk = std::min<long long>(chunk, slice_cap);
