@@ -51,6 +51,9 @@
 #define NVK_GEMV_MAX_ROWS 2 // up to here the vector-ALU GEMV kernel (measured: from 3 rows on its registers allow one
                             // workgroup per CU and the MFMA kernel is as fast); at most 4, 0 switches it off
 #endif
+#ifndef NVK_SKINNY_TM
+#define NVK_SKINNY_TM 1 // 33-96 rows: one wave multiplies 2-3 row tiles by each weight tile (0: separate workgroups per row tile)
+#endif
 #ifndef NVK_SKINNY16_MAX_ROWS
 #define NVK_SKINNY16_MAX_ROWS 16 // up to here the weight-streaming kernel uses 16 x 16 MFMA tiles (0: always 32 x 32)
 #endif
@@ -297,79 +300,91 @@ template <int BM, int BN, int BK> __global__ void __launch_bounds__(256, 2) nvk_
 // than one step's 32 MFMAs), the activations (L2-resident) one step ahead.  No barrier until the waves'
 // partial tiles meet in LDS at the end.  Rows past m are computed on clamped addresses and dropped.
 // With more than 32 rows the row tiles of one column tile are dealt to one XCD (as in the tiled kernel).
-constexpr int kSkinnyBK  = 64;
-constexpr int kSkinnyLds = kSkinnyBK + 4;
 constexpr int kSkinnyWaves = 8;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // T = 32: 32 x 32 tiles on v_mfma_f32_32x32x2_f32.  T = 16 (at most 16 rows): 16 x 16 tiles on
 // v_mfma_f32_16x16x4_f32 -- half the MFMA cycles spent on padding rows, twice the workgroups, half the LDS.
-template <int T> __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
+// TM > 1 (T = 32 only): one wave multiplies TM row tiles by the same weight tile, so up to 32 * TM rows still stream
+// the weights once; BK is then 32 so that the waves' private LDS regions fit.
+template <int T, int TM, int BK>
+__global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
 {
-    constexpr int R = T / 4; // tile rows per lane: a load instruction covers 4 rows x 64 k
-    extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [waves][2][T][kSkinnyLds]
+    constexpr int LDS = BK + 4;             // row stride in LDS (floats)
+    constexpr int LPR = BK / 4, RPI = 64 / LPR; // lanes per tile row, rows per load instruction
+    constexpr int RW = T / RPI, RX = TM * T / RPI; // float4 per lane per step: weights, activations
+    extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [waves][(TM + 1) * T][LDS]
     const int span = 8 * p.m_tiles;
     const int rem  = blockIdx.x % span;
     const int nt   = blockIdx.x / span * 8 + rem % 8;
-    const int m0   = rem / 8 * T;
+    const int m0   = rem / 8 * (TM * T);
     if (nt >= p.n_tiles)
         return;
     const LinearSeg sg = segment_of(p, nt);
     const int       n0 = (nt - sg.tile0) * T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & (T - 1), part = lane / T; // MFMA operand row / column, and which k lanes of the instruction
-    const int lr = lane >> 4, lc = (lane & 15) * 4;
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
 
-    float *sa = s_mem + wave * 2 * T * kSkinnyLds, *sb = sa + T * kSkinnyLds;
-    int    aoff[R], woff[R]; // float offsets of this lane's rows (the host checked they fit an int)
+    constexpr int kRegion = (TM + 1) * T * LDS;
+    float        *sa = s_mem + wave * kRegion, *sb = sa + TM * T * LDS;
+    int           aoff[RX], woff[RW]; // float offsets of this lane's rows (the host checked they fit an int)
 #pragma unroll
-    for (int i = 0; i < R; i++) {
-        aoff[i] = min(m0 + lr + 4 * i, p.m - 1) * p.lda + lc;
-        woff[i] = min(n0 + lr + 4 * i, sg.n - 1) * p.k + lc;
-    }
-    float4 rx[R], rw0[R], rw1[R];
-    auto   fetch_w = [&](float4(&r)[R], int k0) {
+    for (int i = 0; i < RX; i++)
+        aoff[i] = min(m0 + lr + RPI * i, p.m - 1) * p.lda + lc;
+#pragma unroll
+    for (int i = 0; i < RW; i++)
+        woff[i] = min(n0 + lr + RPI * i, sg.n - 1) * p.k + lc;
+    float4 rx[RX], rw0[RW], rw1[RW];
+    auto   fetch_w = [&](float4(&r)[RW], int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
-        for (int i = 0; i < R; i++)
+        for (int i = 0; i < RW; i++)
             r[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto fetch_x = [&](int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
-        for (int i = 0; i < R; i++)
+        for (int i = 0; i < RX; i++)
             rx[i] = inside ? *reinterpret_cast<const float4 *>(p.a + aoff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto stash = [&](const float4(&r)[R]) {
+    auto stash = [&](const float4(&r)[RW]) {
 #pragma unroll
-        for (int i = 0; i < R; i++) {
-            *reinterpret_cast<float4 *>(sa + (lr + 4 * i) * kSkinnyLds + lc) = rx[i];
-            *reinterpret_cast<float4 *>(sb + (lr + 4 * i) * kSkinnyLds + lc) = r[i];
-        }
+        for (int i = 0; i < RX; i++)
+            *reinterpret_cast<float4 *>(sa + (lr + RPI * i) * LDS + lc) = rx[i];
+#pragma unroll
+        for (int i = 0; i < RW; i++)
+            *reinterpret_cast<float4 *>(sb + (lr + RPI * i) * LDS + lc) = r[i];
     };
 
     constexpr int NACC = T == 32 ? 16 : 4; // accumulator registers of one tile
-    f32x16 acc32;
+    f32x16 acc32[TM];
     f32x4  acc16;
 #pragma unroll
-    for (int r = 0; r < 16; r++)
-        acc32[r] = 0.f;
+    for (int t = 0; t < TM; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            acc32[t][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; r++)
         acc16[r] = 0.f;
     // lane (j, part) of MFMA e supplies element 4 * part + e of the chunk (8 wide at T = 32, 16 wide at T = 16)
-    const float *pa = sa + j * kSkinnyLds + 4 * part, *pb = sb + j * kSkinnyLds + 4 * part;
+    const float *pa = sa + j * LDS + 4 * part, *pb = sb + j * LDS + 4 * part;
     auto         multiply = [&]() {
         constexpr int CH = T == 32 ? 8 : 16;
 #pragma unroll
-        for (int c = 0; c < kSkinnyBK / CH; c++) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(pa + CH * c);
+        for (int c = 0; c < BK / CH; c++) {
             const float4 b0 = *reinterpret_cast<const float4 *>(pb + CH * c);
             if constexpr (T == 32) {
-                NVK_MFMA4(a0, b0, acc32)
+#pragma unroll
+                for (int t = 0; t < TM; t++) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(pa + t * T * LDS + CH * c);
+                    NVK_MFMA4(a0, b0, acc32[t])
+                }
             }
             else {
+                const float4 a0 = *reinterpret_cast<const float4 *>(pa + CH * c);
                 acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc16, 0, 0, 0);
                 acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc16, 0, 0, 0);
                 acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc16, 0, 0, 0);
@@ -378,13 +393,13 @@ template <int T> __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_s
         }
     };
 
-    const int nk    = (p.k + kSkinnyBK - 1) / kSkinnyBK;
+    const int nk    = (p.k + BK - 1) / BK;
     const int steps = nk > wave ? (nk - wave + kSkinnyWaves - 1) / kSkinnyWaves : 0; // this wave's share
     // Every workgroup starts the contraction somewhere else (a function of its column tile only, so an output's
     // summation order does not depend on its row): rows of W are in_dim * 4 bytes apart, and workgroups walking k
     // in lockstep would all be asking the same few HBM channels for the same 256-byte column of every row.
     const int rot   = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
-    auto      k_of  = [&](int s) { return ((wave + s * kSkinnyWaves + rot) % nk) * kSkinnyBK; };
+    auto      k_of  = [&](int s) { return ((wave + s * kSkinnyWaves + rot) % nk) * BK; };
     if (steps > 0) {
         fetch_w(rw0, k_of(0));
         fetch_x(k_of(0));
@@ -409,33 +424,39 @@ template <int T> __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_s
     }
 #undef NVK_MFMA4
 
-    // the waves' partial tiles meet in LDS (each wave's own region, NACC x 64 floats); then NACC x 16 threads add
-    // the eight partials of four outputs each, in wave order.  D[row][col]: col = lane % T; register r of lane
+    // the waves' partial tiles meet in LDS (each wave's own region, TM x NACC x 64 floats); then NACC x 16 threads
+    // add the eight partials of four outputs each, in wave order.  D[row][col]: col = lane % T; register r of lane
     // part p holds row (r & 3) + 8 * (r >> 2) + 4 * p at T = 32, row 4 * p + r at T = 16.
+    static_assert(TM * NACC * 64 <= kRegion, "the reduction does not fit the wave's LDS region");
 #pragma unroll
-    for (int r = 0; r < NACC; r++)
-        sa[r * 64 + lane] = T == 32 ? acc32[r] : acc16[r & 3]; // the wave's own region: its operand reads are behind it
+    for (int t = 0; t < TM; t++)
+#pragma unroll
+        for (int r = 0; r < NACC; r++)
+            sa[(t * NACC + r) * 64 + lane] = T == 32 ? acc32[t][r] : acc16[r & 3]; // own region: operand reads are behind us
     __syncthreads();
     if (tid < NACC * 16) {
         const int r = tid >> 4, l4 = (tid & 15) * 4; // register r, lanes l4 .. l4 + 3
-        float4    sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int w = 0; w < kSkinnyWaves; w++) {
-            const float4 v = *reinterpret_cast<const float4 *>(s_mem + w * 2 * T * kSkinnyLds + r * 64 + l4);
-            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
-        }
-        const int pt  = l4 / T; // the four lanes share a part
-        const int row = m0 + (T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * pt : 4 * pt + r);
+        const int pt = l4 / T;                        // the four lanes share a part
         const int col = n0 + (l4 & (T - 1));
-        if (row < p.m) {
-            float *o = sg.out + (int64_t)row * sg.ldo + col;
-            if (col + 3 < sg.n && (sg.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.out) & 15) == 0))
-                *reinterpret_cast<float4 *>(o) = sum;
-            else {
-                if (col < sg.n) o[0] = sum.x;
-                if (col + 1 < sg.n) o[1] = sum.y;
-                if (col + 2 < sg.n) o[2] = sum.z;
-                if (col + 3 < sg.n) o[3] = sum.w;
+#pragma unroll
+        for (int t = 0; t < TM; t++) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < kSkinnyWaves; w++) {
+                const float4 v = *reinterpret_cast<const float4 *>(s_mem + w * kRegion + (t * NACC + r) * 64 + l4);
+                sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+            }
+            const int row = m0 + t * T + (T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * pt : 4 * pt + r);
+            if (row < p.m) {
+                float *o = sg.out + (int64_t)row * sg.ldo + col;
+                if (col + 3 < sg.n && (sg.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.out) & 15) == 0))
+                    *reinterpret_cast<float4 *>(o) = sum;
+                else {
+                    if (col < sg.n) o[0] = sum.x;
+                    if (col + 1 < sg.n) o[1] = sum.y;
+                    if (col + 2 < sg.n) o[2] = sum.z;
+                    if (col + 3 < sg.n) o[3] = sum.w;
+                }
             }
         }
     }
@@ -634,23 +655,34 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
 #endif
     }
     else if (skinny) {
-        const int t = bn; // 16 x 16 tiles for at most 16 rows, else 32 x 32
-        p.m_tiles = (batch + t - 1) / t;
+        // 16 x 16 tiles up to 16 rows; 32 x 32 up to 32; above, one wave carries 2 or 3 row tiles of 32 (NVK_SKINNY_TM)
+        const int t  = bn;
+        const int tm = (t == 32 && NVK_SKINNY_TM && batch > 32) ? (batch + 31) / 32 : 1;
+        const int bk = tm > 1 ? 32 : 64;
+        p.m_tiles = tm > 1 ? 1 : (batch + t - 1) / t;
         const long long wgs = p.m_tiles == 1 ? tiles : (tiles + 7) / 8 * 8 * p.m_tiles;
         if (wgs > 0x7fffffffLL)
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
-        const size_t lds = (size_t)nvk::kSkinnyWaves * 2 * t * nvk::kSkinnyLds * sizeof(float);
-        static bool  opted[64][2]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
-        if (!opted[device & 63][t == 32]) {
-            HIP_TRY(hipFuncSetAttribute(t == 32 ? (const void *)nvk::nvk_gemm_skinny_kernel<32>
-                                                : (const void *)nvk::nvk_gemm_skinny_kernel<16>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            opted[device & 63][t == 32] = true;
+        const size_t lds = (size_t)nvk::kSkinnyWaves * (tm + 1) * t * (bk + 4) * sizeof(float);
+        const void  *fn  = t == 16 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 64>
+                           : tm == 1 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 1, 64>
+                           : tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 2, 32>
+                                     : (const void *)nvk::nvk_gemm_skinny_kernel<32, 3, 32>;
+        const int    slot = t == 16 ? 0 : tm;
+        static bool  opted[64][4]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
+        if (!opted[device & 63][slot]) {
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            opted[device & 63][slot] = true;
         }
-        if (t == 32)
-            hipLaunchKernelGGL(nvk::nvk_gemm_skinny_kernel<32>, dim3((unsigned)wgs), dim3(64 * nvk::kSkinnyWaves), lds, st, p);
+        const dim3 grid((unsigned)wgs), block(64 * nvk::kSkinnyWaves);
+        if (t == 16)
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 1, 64>), grid, block, lds, st, p);
+        else if (tm == 1)
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<32, 1, 64>), grid, block, lds, st, p);
+        else if (tm == 2)
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<32, 2, 32>), grid, block, lds, st, p);
         else
-            hipLaunchKernelGGL(nvk::nvk_gemm_skinny_kernel<16>, dim3((unsigned)wgs), dim3(64 * nvk::kSkinnyWaves), lds, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<32, 3, 32>), grid, block, lds, st, p);
     }
     else {
         p.m_tiles = (batch + bm - 1) / bm;
