@@ -618,8 +618,14 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         for (int s = 0; s < nseg; s++)
             t128 += (n[s] + 127) / 128;
         t128 *= (batch + 127) / 128;
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        static int cu_count[64]; // per device, asked once
+        if (cu_count[device & 63] == 0) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
+                n = 256;
+            cu_count[device & 63] = n;
+        }
+        const int cus = cu_count[device & 63];
         // measured (profiles/r01_qkv_projection.log): two 128 x 128 workgroups fit a CU, and a launch that is not
         // at least three full rounds of them loses more to the ragged last round than 64 x 64 tiles lose to their
         // four times higher LDS and L2 traffic per flop

@@ -27,6 +27,15 @@ def batch_matmul_device(out_dev, in_dev, weight_dev, batch_size: int, in_dim: in
                                                   int(in_dim), int(out_dim), int(device), _devptr(stream)))
 
 
+def batch_matmul2_device(out_a_dev, out_b_dev, in_dev, weight_a_dev, weight_b_dev, batch_size: int, in_dim: int,
+                          out_dim_a: int, out_dim_b: int, device: int = 0, stream=None) -> None:
+    """Two products over the same activations in one launch (w_gate and w_up, model.hpp:232-233)."""
+    _capi.check(_capi.lib.nvk_batch_matmul2_device(_devptr(out_a_dev), _devptr(out_b_dev), _devptr(in_dev),
+                                                   _devptr(weight_a_dev), _devptr(weight_b_dev), int(batch_size),
+                                                   int(in_dim), int(out_dim_a), int(out_dim_b), int(device),
+                                                   _devptr(stream)))
+
+
 def qkv_project_device(q_dev, k_dev, v_dev, x_dev, xb_dev, rms_weight_dev, wq_dev, wk_dev, wv_dev, batch_size: int,
                        dim: int, q_dim: int, kv_dim: int, rms_eps: float = RMS_EPS, device: int = 0, stream=None) -> None:
     """xb = rms_norm(x, rms_weight); q, k, v = wq.xb, wk.xb, wv.xb in one launch (model.hpp:161-166)."""

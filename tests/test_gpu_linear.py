@@ -150,6 +150,26 @@ def test_qkv_feeds_rope_append_and_decode(nv, DA):
         assert close(got[s], want), (s, float(np.abs(got[s] - want).max()))
 
 
+@pytest.mark.parametrize("B", [1, 7, 40, 150])
+def test_two_products_in_one_launch(B, nv, DA):
+    """nvk_batch_matmul2_device (w_gate | w_up, model.hpp:232-233): both outputs equal the single-product calls bit for
+    bit (same kernel, same column tiles' summation order) and the checker within the bar."""
+    D, NA, NB = 96, 200, 72
+    x = uniform(1100 + B, 0, B * D).reshape(B, D)
+    wa = (uniform(1101, 0, NA * D) * np.float32(0.1)).reshape(NA, D)
+    wb = (uniform(1102, 0, NB * D) * np.float32(0.1)).reshape(NB, D)
+    dx, dwa, dwb = DA(x), DA(wa), DA(wb)
+    oa, ob = DA(np.full((B, NA), np.nan, np.float32)), DA(np.full((B, NB), np.nan, np.float32))
+    nv.batch_matmul2_device(oa, ob, dx, dwa, dwb, B, D, NA, NB)
+    sa, sb = DA(np.zeros((B, NA), np.float32)), DA(np.zeros((B, NB), np.float32))
+    nv.batch_matmul_device(sa, dx, dwa, B, D, NA)
+    nv.batch_matmul_device(sb, dx, dwb, B, D, NB)
+    assert close(oa.numpy(), ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x, wa))
+    assert close(ob.numpy(), ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x, wb))
+    assert np.array_equal(oa.numpy(), sa.numpy())
+    assert close(ob.numpy(), sb.numpy())  # the second segment's tiles start elsewhere in k than in a launch of its own
+
+
 def test_argument_errors(nv, DA):
     a = DA(np.zeros((4, 8), np.float32))
     with pytest.raises(nv.NvkError):
