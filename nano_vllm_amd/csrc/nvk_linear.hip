@@ -111,10 +111,25 @@ __global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ o
     float           *y = out + (int64_t)blockIdx.x * dim;
     float            ss = 0.f;
     const int        vec = (dim % 4 == 0) ? dim / 4 : 0;
-    for (int i = threadIdx.x; i < vec; i += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(x + 4 * i);
-        ss = fmaf(v.x, v.x, ss), ss = fmaf(v.y, v.y, ss), ss = fmaf(v.z, v.z, ss), ss = fmaf(v.w, v.w, ss);
+    // rows of up to 8192 floats stay in registers between the two passes (one read of x instead of two)
+    constexpr int KEEP = 8;
+    const bool    keep = vec <= KEEP * 256;
+    float4        held[KEEP];
+#pragma unroll
+    for (int u = 0; u < KEEP; u++) {
+        const int i = threadIdx.x + 256 * u;
+        held[u]     = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (keep && i < vec) {
+            held[u] = *reinterpret_cast<const float4 *>(x + 4 * i);
+            ss = fmaf(held[u].x, held[u].x, ss), ss = fmaf(held[u].y, held[u].y, ss);
+            ss = fmaf(held[u].z, held[u].z, ss), ss = fmaf(held[u].w, held[u].w, ss);
+        }
     }
+    if (!keep)
+        for (int i = threadIdx.x; i < vec; i += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + 4 * i);
+            ss = fmaf(v.x, v.x, ss), ss = fmaf(v.y, v.y, ss), ss = fmaf(v.z, v.z, ss), ss = fmaf(v.w, v.w, ss);
+        }
     for (int i = 4 * vec + threadIdx.x; i < dim; i += 256)
         ss = fmaf(x[i], x[i], ss);
 #pragma unroll
@@ -127,13 +142,27 @@ __global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ o
     const float rms = 1.0f / sqrtf(ss / dim + eps);
     {
 #pragma clang fp contract(off) // (in * rms) * weight, two roundings, as the reference's expression
-        for (int i = threadIdx.x; i < vec; i += 256) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + 4 * i);
-            const float4 g = *reinterpret_cast<const float4 *>(weight + 4 * i);
-            float4       r;
-            r.x = v.x * rms * g.x, r.y = v.y * rms * g.y, r.z = v.z * rms * g.z, r.w = v.w * rms * g.w;
-            *reinterpret_cast<float4 *>(y + 4 * i) = r;
+        if (keep) {
+#pragma unroll
+            for (int u = 0; u < KEEP; u++) {
+                const int i = threadIdx.x + 256 * u;
+                if (i < vec) {
+                    const float4 v = held[u];
+                    const float4 g = *reinterpret_cast<const float4 *>(weight + 4 * i);
+                    float4       r;
+                    r.x = v.x * rms * g.x, r.y = v.y * rms * g.y, r.z = v.z * rms * g.z, r.w = v.w * rms * g.w;
+                    *reinterpret_cast<float4 *>(y + 4 * i) = r;
+                }
+            }
         }
+        else
+            for (int i = threadIdx.x; i < vec; i += 256) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + 4 * i);
+                const float4 g = *reinterpret_cast<const float4 *>(weight + 4 * i);
+                float4       r;
+                r.x = v.x * rms * g.x, r.y = v.y * rms * g.y, r.z = v.z * rms * g.z, r.w = v.w * rms * g.w;
+                *reinterpret_cast<float4 *>(y + 4 * i) = r;
+            }
         for (int i = 4 * vec + threadIdx.x; i < dim; i += 256)
             y[i] = x[i] * rms * weight[i];
     }

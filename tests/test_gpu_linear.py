@@ -57,7 +57,7 @@ def test_golden_qkv_cases(case, nv, DA, golden_dir):
 
 
 def test_rms_norm_rows_and_in_place(nv, DA):
-    for seed, (B, D) in enumerate([(1, 4096), (7, 288), (300, 1024), (3, 6), (2, 4100)]):
+    for seed, (B, D) in enumerate([(1, 4096), (7, 288), (300, 1024), (3, 6), (2, 4100), (2, 9000), (3, 8192)]):
         x = (uniform(800 + seed, 0, B * D) * np.float32(3)).reshape(B, D)
         g = uniform(810 + seed, 0, D) + np.float32(1.25)
         want = ol.batch_rms_norm(ol.ORACLE.oracle_batch_rms_norm, x, g)
