@@ -109,6 +109,10 @@ struct nvk_pool
     // staging for the host-pointer entry points
     char  *stage     = nullptr;
     size_t stage_cap = 0;
+    // pinned host twin of the head of `stage` for nvk_decode: q | tables | lengths go to the device in ONE copy and
+    // `out` comes back through it (copies from pageable memory cost the runtime a staging step and a wait each)
+    char  *pin     = nullptr;
+    size_t pin_cap = 0;
 
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
 
@@ -141,6 +145,22 @@ int ensure_stage(nvk_pool *pool, size_t bytes)
     const size_t want = std::max(bytes, (size_t)1 << 20);
     HIP_TRY(hipMalloc(&pool->stage, want));
     pool->stage_cap = want;
+    return NVK_OK;
+}
+
+int ensure_pin(nvk_pool *pool, size_t bytes)
+{
+    if (bytes <= pool->pin_cap)
+        return NVK_OK;
+    if (pool->pin) {
+        HIP_TRY(hipStreamSynchronize(pool->stream));
+        HIP_TRY(hipHostFree(pool->pin));
+        pool->pin     = nullptr;
+        pool->pin_cap = 0;
+    }
+    const size_t want = std::max(bytes, (size_t)1 << 18);
+    HIP_TRY(hipHostMalloc((void **)&pool->pin, want, hipHostMallocDefault));
+    pool->pin_cap = want;
     return NVK_OK;
 }
 
@@ -265,6 +285,9 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
         chunk = round_up((int)std::min<long long>(1 << 20, (tokens_upper + pool->num_cus - 1) / pool->num_cus),
                          NVK_AUTO_MIN_CHUNK);
         chunk = std::max<long long>(NVK_AUTO_MIN_CHUNK, std::min<long long>(chunk, NVK_AUTO_MAX_CHUNK));
+        // at most 128 chunks per sequence: the merge walks a sequence's partials one after the other (one long
+        // sequence alone, 32K tokens: 171 us with 256 chunks of 128, 134 us with 128 chunks of 256)
+        chunk = std::max<long long>(chunk, round_up((ctx_cap + 127) / 128, NVK_AUTO_MIN_CHUNK));
     }
     chunk = std::min<long long>(chunk, ctx_cap);
     chunk = std::min<long long>(chunk, slice_cap);
@@ -913,6 +936,8 @@ int nvk_pool_destroy(nvk_pool *pool)
         (void)hipEventDestroy(pool->desc_ev);
     if (pool->stage)
         (void)hipFree(pool->stage);
+    if (pool->pin)
+        (void)hipHostFree(pool->pin);
     if (pool->ev_a)
         (void)hipEventDestroy(pool->ev_a);
     if (pool->ev_b)
@@ -1345,22 +1370,87 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
     const size_t tab_a = (tab_b + 255) / 256 * 256;
     const size_t ctx_b = (size_t)num_seqs * sizeof(int);
     const size_t ctx_a = (ctx_b + 255) / 256 * 256;
-    rc                 = ensure_stage(pool, 2 * q_a + tab_a + ctx_a);
+    // device staging: q | tables | lengths | plan | out.  Small batches go through the pinned twin in one copy each
+    // way, and their plan (the lengths are host data here) is built on the host and travels in the same copy instead
+    // of costing a kernel: a single-sequence call is bound by latency, not by bandwidth.
+    LaunchShape sh;
+    rc = make_shape(pool, num_seqs, n_heads, max_ctx, flags, chunk_tokens, &sh);
     if (rc != NVK_OK)
         return rc;
-    float *dq   = (float *)pool->stage;
-    float *dout = (float *)(pool->stage + q_a);
-    int   *dtab = (int *)(pool->stage + 2 * q_a);
-    int   *dctx = (int *)(pool->stage + 2 * q_a + tab_a);
-    HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, pool->stream));
-    HIP_TRY(hipMemcpyAsync(dtab, block_tables, tab_b, hipMemcpyHostToDevice, pool->stream));
-    HIP_TRY(hipMemcpyAsync(dctx, ctx_lens, ctx_b, hipMemcpyHostToDevice, pool->stream));
-    rc = enqueue_decode(pool, layer, num_seqs, n_heads, dq, dtab, max_blocks, dctx, max_ctx, dout, flags, chunk_tokens,
-                        pool->stream);
+    const long long bound   = (long long)num_seqs * sh.max_chunks;
+    const size_t    cnt_a   = ((size_t)(num_seqs + 1) * sizeof(int) + 255) / 256 * 256;
+    const size_t    items_a = ((size_t)bound * sizeof(nvk::WorkItem) + 255) / 256 * 256;
+    const bool      pinned  = bound <= 0x7fffffffLL && q_a + tab_a + ctx_a + cnt_a + items_a + q_a <= ((size_t)4 << 20);
+    if (!pinned) { // beyond a few MB the extra host memcpy is not worth it: separate copies, plan kernel
+        rc = ensure_stage(pool, 2 * q_a + tab_a + ctx_a);
+        if (rc != NVK_OK)
+            return rc;
+        float *dq   = (float *)pool->stage;
+        float *dout = (float *)(pool->stage + q_a);
+        int   *dtab = (int *)(pool->stage + 2 * q_a);
+        int   *dctx = (int *)(pool->stage + 2 * q_a + tab_a);
+        HIP_TRY(hipMemcpyAsync(dq, q, q_b, hipMemcpyHostToDevice, pool->stream));
+        HIP_TRY(hipMemcpyAsync(dtab, block_tables, tab_b, hipMemcpyHostToDevice, pool->stream));
+        HIP_TRY(hipMemcpyAsync(dctx, ctx_lens, ctx_b, hipMemcpyHostToDevice, pool->stream));
+        rc = enqueue_decode(pool, layer, num_seqs, n_heads, dq, dtab, max_blocks, dctx, max_ctx, dout, flags,
+                            chunk_tokens, pool->stream);
+        if (rc != NVK_OK)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(out, dout, q_b, hipMemcpyDeviceToHost, pool->stream));
+        HIP_TRY(hipStreamSynchronize(pool->stream));
+        return NVK_OK;
+    }
+    const size_t off_tab = q_a, off_ctx = off_tab + tab_a, off_cnt = off_ctx + ctx_a, off_items = off_cnt + cnt_a;
+    const size_t in_bytes = off_items + items_a;
+    rc = ensure_stage(pool, in_bytes + q_a);
+    if (rc == NVK_OK)
+        rc = ensure_pin(pool, in_bytes + q_a);
+    if (rc == NVK_OK && sh.max_chunks > 1)
+        rc = ensure_workspace(pool, (size_t)bound * n_heads * pool->head_dim, (size_t)bound * n_heads * 2);
     if (rc != NVK_OK)
         return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout, q_b, hipMemcpyDeviceToHost, pool->stream));
+    std::memcpy(pool->pin, q, q_b);
+    std::memcpy(pool->pin + off_tab, block_tables, tab_b);
+    std::memcpy(pool->pin + off_ctx, ctx_lens, ctx_b);
+    {
+        // the plan nvk_plan_kernel would build: full chunks sequence-major, then the ragged last chunks by decreasing
+        // length (empty sequences last); the order only shapes the grid's tail, never a result
+        int           *cnt   = reinterpret_cast<int *>(pool->pin + off_cnt);
+        nvk::WorkItem *items = reinterpret_cast<nvk::WorkItem *>(pool->pin + off_items);
+        const int      ct    = sh.chunk_tokens;
+        int            n     = 0;
+        for (int s2 = 0; s2 < num_seqs; s2++) {
+            const int ctx = std::min(ctx_lens[s2], sh.max_chunks * ct), nfull = ctx / ct, rem = ctx - nfull * ct;
+            const int nch = nfull + (rem > 0 ? 1 : 0);
+            cnt[1 + s2]   = nch;
+            for (int c = 0; c < nfull; c++)
+                items[n++] = nvk::WorkItem{s2, c | (nch << 16), c * ct, (c + 1) * ct};
+        }
+        const int first_partial = n;
+        for (int s2 = 0; s2 < num_seqs; s2++) {
+            const int ctx = std::min(ctx_lens[s2], sh.max_chunks * ct), nfull = ctx / ct, rem = ctx - nfull * ct;
+            if (rem > 0 || ctx == 0)
+                items[n++] = nvk::WorkItem{s2, nfull | ((nfull + (rem > 0 ? 1 : 0)) << 16), nfull * ct, ctx};
+        }
+        std::stable_sort(items + first_partial, items + n, [](const nvk::WorkItem &x, const nvk::WorkItem &y) {
+            return x.t1 - x.t0 > y.t1 - y.t0;
+        });
+        cnt[0] = n;
+    }
+    HIP_TRY(hipMemcpyAsync(pool->stage, pool->pin, in_bytes, hipMemcpyHostToDevice, pool->stream));
+    nvk_plan host_plan; // lives for this call only; its device arrays are slices of the staging buffer
+    host_plan.pool = pool, host_plan.num_seqs = num_seqs, host_plan.n_heads = n_heads, host_plan.max_ctx = max_ctx;
+    host_plan.shape = sh, host_plan.built = true, host_plan.item_bound = (int)bound;
+    host_plan.items    = reinterpret_cast<nvk::WorkItem *>(pool->stage + off_items);
+    host_plan.counters = reinterpret_cast<int *>(pool->stage + off_cnt);
+    float *dout = (float *)(pool->stage + in_bytes);
+    rc = enqueue_planned(pool, layer, &host_plan, (const float *)pool->stage, (const int *)(pool->stage + off_tab), max_blocks,
+                         dout, pool->stream, nullptr, nullptr);
+    if (rc != NVK_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(pool->pin + in_bytes, dout, q_b, hipMemcpyDeviceToHost, pool->stream));
     HIP_TRY(hipStreamSynchronize(pool->stream));
+    std::memcpy(out, pool->pin + in_bytes, q_b);
     return NVK_OK;
 }
 
