@@ -23,6 +23,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "nvk_device_scope.h"
 #include "nvk_internal.h"
 
 #define HIP_TRY(expr)                                                                                                  \
@@ -55,22 +56,6 @@ struct Slot
     int              request_id = -1;
     int              len        = 0; // tokens whose K/V are in the pool
     std::vector<int> blocks;         // = Request::block_ids
-};
-
-struct DeviceScope
-{
-    int previous = -1;
-    explicit DeviceScope(int device)
-    {
-        if (hipGetDevice(&previous) != hipSuccess)
-            previous = -1;
-        (void)hipSetDevice(device);
-    }
-    ~DeviceScope()
-    {
-        if (previous >= 0)
-            (void)hipSetDevice(previous);
-    }
 };
 
 } // namespace
@@ -127,7 +112,7 @@ void release(nvk_batch *b)
 {
     if (!b)
         return;
-    DeviceScope scope(b->device);
+    nvk::DeviceScope scope(b->device);
     (void)hipDeviceSynchronize();
     if (b->plan)
         (void)nvk_plan_destroy(b->plan);
@@ -173,7 +158,7 @@ int nvk_batch_create(nvk_pool *pool, nvk_block_manager *bm, int max_seqs, int ma
     b->pool = pool, b->bm = bm, b->max_seqs = max_seqs, b->max_blocks = max_blocks_per_seq;
     b->block_size = geo[2], b->device = geo[5];
     b->row_len = geo[3] * geo[4], b->head_dim = geo[4];
-    DeviceScope  scope(b->device);
+    nvk::DeviceScope  scope(b->device);
     const size_t tab = (size_t)max_seqs * max_blocks_per_seq * sizeof(int);
     const size_t vec = (size_t)max_seqs * sizeof(int);
     hipError_t   e   = hipHostMalloc((void **)&b->h_tables, tab, hipHostMallocDefault);
@@ -245,7 +230,7 @@ int nvk_batch_finish_request(nvk_batch *b, int request_id)
     // Kernels of earlier steps may still be reading this request's blocks: they must be done
     // before the ids can be handed to another request.
     {
-        DeviceScope scope(b->device);
+        nvk::DeviceScope scope(b->device);
         HIP_TRY(hipDeviceSynchronize());
     }
     nvk_bm_free_request(b->bm, request_id); // ref: BlockManager::free_request, block_manager.hpp:157-171
@@ -329,7 +314,7 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
         return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks (%d needed, %d free)", need,
                          nvk_bm_num_free_blocks(b->bm)); // the reference's text, model.hpp:184
 
-    DeviceScope scope(b->device);
+    nvk::DeviceScope scope(b->device);
     hipStream_t st = stream_or_pool(b, stream);
     HIP_TRY(hipEventSynchronize(b->staged)); // the pinned buffers are ours again
 
@@ -452,7 +437,7 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
         return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks (%lld needed, %d free)", need,
                          nvk_bm_num_free_blocks(b->bm));
 
-    DeviceScope scope(b->device);
+    nvk::DeviceScope scope(b->device);
     hipStream_t st = stream_or_pool(b, stream);
     HIP_TRY(hipEventSynchronize(b->staged));
     b->resident_valid = false; // rows of a mixed step are not the decode list: the next decode step re-sends its tables
@@ -538,7 +523,7 @@ int nvk_batch_layer(nvk_batch *b, int layer, float *q_dev, const float *k_rows_d
         return NVK_OK;
     if (!q_dev || !k_rows_dev || !v_rows_dev || !out_dev || rope_theta < 0.f)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_layer: bad arguments");
-    DeviceScope scope(b->device);
+    nvk::DeviceScope scope(b->device);
     hipStream_t st = stream_or_pool(b, stream);
     if (b->chunked) {
         // decode part: rows [0, nd), one per request; prefill part: the chunks' rows packed behind them
@@ -592,7 +577,7 @@ int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim,
     if (rows < 0)
         return rows;
     const size_t qdim = (size_t)b->n_heads * b->head_dim;
-    DeviceScope  scope(b->device);
+    nvk::DeviceScope  scope(b->device);
     hipStream_t  st = stream_or_pool(b, stream);
     if ((size_t)rows > b->h_rows || (size_t)dim > b->h_dim || qdim > b->h_qdim) {
         // grow the scratch rows: earlier launches may still use the old ones

@@ -1,0 +1,45 @@
+// nvk_device_scope.h -- makes a device current for a scope (HIP translation units only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace nvk {
+
+// Makes `device` current and restores the caller's device after; when it already is current (the usual case: one
+// process per GPU) nothing is set or restored -- the entry points are called hundreds of times per model step.
+struct DeviceScope
+{
+    int  previous = -1;
+    bool ok       = true;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&previous) != hipSuccess)
+            previous = -1;
+        if (previous == device)
+            previous = -1; // nothing to do, nothing to undo
+        else
+            ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (previous >= 0)
+            (void)hipSetDevice(previous);
+    }
+    DeviceScope(const DeviceScope &)            = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+// hipGetDeviceCount, asked once per process (0 when no device is visible or the runtime fails)
+inline int device_count_cached()
+{
+    static int cached = 0;
+    if (cached > 0)
+        return cached;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return 0; // keep asking while there is none
+    cached = n;
+    return n;
+}
+
+} // namespace nvk

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 
+#include "nvk_device_scope.h"
 #include "nvk_internal.h"
 
 #define HIP_TRY(expr)                                                                                                  \
@@ -594,27 +595,10 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
 
 namespace {
 
-struct DeviceScope
-{
-    int  previous = -1;
-    bool ok       = false;
-    explicit DeviceScope(int device)
-    {
-        if (hipGetDevice(&previous) != hipSuccess)
-            previous = -1;
-        ok = hipSetDevice(device) == hipSuccess;
-    }
-    ~DeviceScope()
-    {
-        if (previous >= 0)
-            (void)hipSetDevice(previous);
-    }
-};
-
 int check_device(int device, const char *who)
 {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    const int ndev = nvk::device_count_cached();
+    if (ndev <= 0)
         return nvk::fail(NVK_ERR_NO_DEVICE, "%s: no HIP device visible (this library has no CPU path)", who);
     if (device < 0 || device >= ndev)
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: device %d outside [0,%d)", who, device, ndev);
@@ -765,7 +749,7 @@ int nvk_batch_rms_norm_device(float *out_dev, const float *in_dev, const float *
         return rc;
     if (dim % 4 == 0 && (!aligned16(out_dev) || !aligned16(in_dev) || !aligned16(weight_dev)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_rms_norm_device: pointers must be 16-byte aligned");
-    DeviceScope scope(device);
+    nvk::DeviceScope scope(device);
     hipLaunchKernelGGL(nvk::nvk_rms_norm_kernel, dim3((unsigned)batch_size), dim3(256), 0, (hipStream_t)stream, out_dev,
                        in_dev, weight_dev, dim, eps);
     HIP_TRY(hipGetLastError());
@@ -780,7 +764,7 @@ int nvk_batch_matmul_device(float *out_dev, const float *in_dev, const float *we
     int rc = check_device(device, "nvk_batch_matmul_device");
     if (rc != NVK_OK || batch_size == 0)
         return rc;
-    DeviceScope scope(device);
+    nvk::DeviceScope scope(device);
     return launch_linear(in_dev, batch_size, in_dim, &weight_dev, &out_dev, &out_dim, 1, device, (hipStream_t)stream,
                          "nvk_batch_matmul_device");
 }
@@ -795,7 +779,7 @@ int nvk_batch_matmul2_device(float *out_a_dev, float *out_b_dev, const float *in
     int rc = check_device(device, "nvk_batch_matmul2_device");
     if (rc != NVK_OK || batch_size == 0)
         return rc;
-    DeviceScope        scope(device);
+    nvk::DeviceScope        scope(device);
     const float *const w[2]   = {weight_a_dev, weight_b_dev};
     float *const       out[2] = {out_a_dev, out_b_dev};
     const int          n[2]   = {out_dim_a, out_dim_b};
@@ -820,7 +804,7 @@ int nvk_qkv_project_device(float *q_dev, float *k_dev, float *v_dev, const float
             return rc;
         act = xb_dev;
     }
-    DeviceScope        scope(device);
+    nvk::DeviceScope        scope(device);
     const float *const w[3]   = {wq_dev, wk_dev, wv_dev}; // model.hpp:164-166
     float *const       out[3] = {q_dev, k_dev, v_dev};
     const int          n[3]   = {q_dim, kv_dim, kv_dim};

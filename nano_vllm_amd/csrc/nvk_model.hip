@@ -22,6 +22,7 @@
 #include <cstring>
 #include <vector>
 
+#include "nvk_device_scope.h"
 #include "nvk_internal.h"
 
 #define HIP_TRY(expr)                                                                                                  \
@@ -105,22 +106,6 @@ __global__ void __launch_bounds__(256) nvk_argmax_kernel(int *__restrict__ next,
         next[blockIdx.x] = s_i[0] == 0x7fffffff ? 0 : s_i[0];
 }
 
-struct DeviceScope
-{
-    int previous = -1;
-    explicit DeviceScope(int device)
-    {
-        if (hipGetDevice(&previous) != hipSuccess)
-            previous = -1;
-        (void)hipSetDevice(device);
-    }
-    ~DeviceScope()
-    {
-        if (previous >= 0)
-            (void)hipSetDevice(previous);
-    }
-};
-
 struct LayerWeights
 {
     const float *rms_att, *wq, *wk, *wv, *wo, *rms_ffn, *w_gate, *w_down, *w_up;
@@ -158,7 +143,7 @@ void release(nvk_model *m)
 {
     if (!m)
         return;
-    DeviceScope scope(m->device);
+    nvk::DeviceScope scope(m->device);
     (void)hipDeviceSynchronize();
     if (m->batch)
         (void)nvk_batch_destroy(m->batch);
@@ -274,7 +259,7 @@ int nvk_model_load(const char *checkpoint_path, int block_size, int num_blocks, 
     }
     m->dim = D, m->hidden_dim = Hd, m->n_layers = L, m->n_heads = H, m->n_kv_heads = KV, m->vocab = V, m->max_seq_len = S;
     m->head_dim = hd, m->shared = !has_head, m->device = device, m->max_seqs = max_seqs;
-    DeviceScope scope(device);
+    nvk::DeviceScope scope(device);
 
     // stream the file to the device in 64 MiB pieces through one pinned buffer
     hipError_t e = hipMalloc((void **)&m->weights, total * sizeof(float));
@@ -410,7 +395,7 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
     }
     if (rows > 0x3fffffffLL)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: %lld rows in one step", rows);
-    DeviceScope scope(m->device);
+    nvk::DeviceScope scope(m->device);
     int         rc = reserve_rows(m, (int)rows);
     if (rc != NVK_OK)
         return rc;

@@ -14,6 +14,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "nvk_device_scope.h"
 #include "nvk_internal.h"
 #include "nvk_kernels.hip.h"
 
@@ -57,24 +58,6 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 namespace {
-
-// Makes `device` current for the scope and restores the caller's device after.
-struct DeviceScope
-{
-    int  previous = -1;
-    bool ok       = false;
-    explicit DeviceScope(int device)
-    {
-        if (hipGetDevice(&previous) != hipSuccess)
-            previous = -1;
-        ok = hipSetDevice(device) == hipSuccess;
-    }
-    ~DeviceScope()
-    {
-        if (previous >= 0)
-            (void)hipSetDevice(previous);
-    }
-};
 
 // ceil(2^32 / block_size) for nvk::token_block; 0 stands for block_size 1
 unsigned division_magic(int block_size)
@@ -850,7 +833,7 @@ int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads
     if (device < 0 || device >= ndev)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_create: device %d outside [0,%d)", device, ndev);
 
-    DeviceScope scope(device);
+    nvk::DeviceScope scope(device);
     if (!scope.ok)
         return nvk::fail(NVK_ERR_HIP, "nvk_pool_create: hipSetDevice(%d) failed", device);
 
@@ -904,7 +887,7 @@ int nvk_pool_set_rope_theta(nvk_pool *pool, float rope_theta)
 {
     if (!pool || !(rope_theta > 0.f) || pool->head_dim % 2 != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_set_rope_theta: bad arguments");
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     return ensure_rope_table(pool, rope_theta);
 }
 
@@ -912,7 +895,7 @@ int nvk_pool_destroy(nvk_pool *pool)
 {
     if (!pool)
         return NVK_OK;
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     if (t_bound_pool == pool)
         t_bound_pool = nullptr;
     if (pool->stream)
@@ -981,7 +964,7 @@ int nvk_pool_synchronize(nvk_pool *pool)
 {
     if (!pool)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_synchronize: null pool");
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     HIP_TRY(hipStreamSynchronize(pool->stream));
     return NVK_OK;
 }
@@ -1000,7 +983,7 @@ int nvk_pool_append(nvk_pool *pool, int layer, int physical_block, int block_off
     if (block_offset < 0 || block_offset >= pool->block_size)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append: offset %d outside [0,%d)", block_offset,
                          pool->block_size);
-    DeviceScope  scope(pool->device);
+    nvk::DeviceScope  scope(pool->device);
     const size_t row = (size_t)pool->row_len();
     const size_t at  = ((size_t)physical_block * pool->block_size + block_offset) * row;
     HIP_TRY(hipMemcpyAsync(pool->k_layer(layer) + at, k_row, row * sizeof(float), hipMemcpyHostToDevice, pool->stream));
@@ -1020,7 +1003,7 @@ int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append_batch: bad arguments");
     if (num_seqs == 0)
         return NVK_OK;
-    DeviceScope  scope(pool->device);
+    nvk::DeviceScope  scope(pool->device);
     const int    row = pool->row_len();
     const float *dk = k_rows, *dv = v_rows;
     const int   *dt = block_tables, *dp = positions;
@@ -1081,7 +1064,7 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: head_dim must be even");
     if (num_seqs == 0)
         return NVK_OK;
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     hipStream_t st   = (ptr_kind == NVK_PTR_DEVICE && stream) ? (hipStream_t)stream : pool->stream;
     const int   hd   = pool->head_dim;
     const int   half = hd / 2;
@@ -1152,7 +1135,7 @@ int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const f
     if (physical_block < 0 || physical_block >= pool->num_blocks)
         return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_upload_block: block %d outside [0,%d)", physical_block,
                          pool->num_blocks);
-    DeviceScope  scope(pool->device);
+    nvk::DeviceScope  scope(pool->device);
     const size_t blk = (size_t)pool->block_size * pool->row_len();
     if (k_block)
         HIP_TRY(hipMemcpyAsync(pool->k_layer(layer) + physical_block * blk, k_block, blk * sizeof(float),
@@ -1172,7 +1155,7 @@ int nvk_pool_download_block(nvk_pool *pool, int layer, int physical_block, float
     if (physical_block < 0 || physical_block >= pool->num_blocks)
         return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_download_block: block %d outside [0,%d)", physical_block,
                          pool->num_blocks);
-    DeviceScope  scope(pool->device);
+    nvk::DeviceScope  scope(pool->device);
     const size_t blk = (size_t)pool->block_size * pool->row_len();
     if (k_block)
         HIP_TRY(hipMemcpyAsync(k_block, pool->k_layer(layer) + physical_block * blk, blk * sizeof(float),
@@ -1199,7 +1182,7 @@ int nvk_pool_gather(nvk_pool *pool, int layer, const int *block_table, int num_t
         if (block_table[i] < 0 || block_table[i] >= pool->num_blocks)
             return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_gather: table[%d]=%d outside [0,%d)", i, block_table[i],
                              pool->num_blocks);
-    DeviceScope  scope(pool->device);
+    nvk::DeviceScope  scope(pool->device);
     const size_t out_b = (size_t)num_tokens * pool->head_dim * sizeof(float);
     const size_t out_a = (out_b + 255) / 256 * 256;
     const size_t tab_b = (size_t)nblk * sizeof(int);
@@ -1225,7 +1208,7 @@ int nvk_pool_fill_uniform(nvk_pool *pool, int layer, uint64_t seed_k, uint64_t s
     int rc = check_pool_layer(pool, layer, "nvk_pool_fill_uniform");
     if (rc != NVK_OK)
         return rc;
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     const dim3  grid((unsigned)(pool->num_cus * 8)), block(256);
     hipLaunchKernelGGL(nvk::nvk_fill_kernel, grid, block, 0, pool->stream, pool->k_layer(layer), seed_k,
                        (uint64_t)pool->layer_floats);
@@ -1241,7 +1224,7 @@ int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int ma
 {
     if (!pool || num_seqs < 0 || max_ctx < 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_reserve_workspace: bad arguments");
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     LaunchShape shape;
     int rc = make_shape(pool, num_seqs, n_heads, max_ctx, chunk_tokens > 0 ? NVK_DECODE_SPLIT_K : NVK_DECODE_AUTO,
                         chunk_tokens, &shape);
@@ -1274,7 +1257,7 @@ int nvk_plan_destroy(nvk_plan *plan)
 {
     if (!plan)
         return NVK_OK;
-    DeviceScope scope(plan->pool->device);
+    nvk::DeviceScope scope(plan->pool->device);
     (void)hipDeviceSynchronize();
     free_plan(plan);
     return NVK_OK;
@@ -1287,7 +1270,7 @@ int nvk_plan_build(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_len
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: bad arguments");
     if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: flags %d", flags);
-    DeviceScope scope(plan->pool->device);
+    nvk::DeviceScope scope(plan->pool->device);
     return build_plan(plan, num_seqs, n_heads, ctx_lens_dev, max_ctx, flags, chunk_tokens,
                       stream ? (hipStream_t)stream : plan->pool->stream);
 }
@@ -1309,7 +1292,7 @@ int nvk_decode_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const fl
         return rc;
     if (!plan || max_blocks <= 0 || (plan->num_seqs > 0 && (!q_dev || !block_tables_dev || !out_dev)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_planned: bad arguments");
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     return enqueue_planned(pool, layer, plan, q_dev, block_tables_dev, max_blocks, out_dev,
                            stream ? (hipStream_t)stream : pool->stream, nullptr, nullptr);
 }
@@ -1326,7 +1309,7 @@ int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, cons
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: bad arguments");
     if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: flags %d", flags);
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     return enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
                           out_dev, flags, chunk_tokens, stream ? (hipStream_t)stream : pool->stream);
 }
@@ -1363,7 +1346,7 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
         max_ctx = std::max(max_ctx, ctx);
     }
 
-    DeviceScope  scope(pool->device);
+    nvk::DeviceScope  scope(pool->device);
     const size_t q_b   = (size_t)num_seqs * n_heads * pool->head_dim * sizeof(float);
     const size_t q_a   = (q_b + 255) / 256 * 256;
     const size_t tab_b = (size_t)num_seqs * max_blocks * sizeof(int);
@@ -1465,7 +1448,7 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
     if (iters < 0 || warmup < 0 || num_seqs <= 0 || iters > 100000 || replan_every < 1)
         return nvk::fail(NVK_ERR_INVALID_ARG,
                          "nvk_decode_bench: need 0 <= iters <= 100000, warmup >= 0, num_seqs > 0, replan_every >= 1");
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     hipStream_t st   = pool->stream;
     nvk_plan   *plan = nullptr;
     rc               = own_plan_of(pool, &plan);
@@ -1554,7 +1537,7 @@ int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_h
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_chunks: ptr_kind %d", ptr_kind);
     if (num_seqs == 0)
         return NVK_OK;
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     hipStream_t st = (ptr_kind == NVK_PTR_DEVICE && stream) ? (hipStream_t)stream : pool->stream;
     if (ptr_kind == NVK_PTR_HOST) {
         rc = validate_chunk_tables(pool, num_seqs, block_tables, max_blocks, chunk_starts, chunk_lens,
@@ -1622,7 +1605,7 @@ int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, con
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_prefill_device: flags %d", flags);
     if (num_seqs == 0)
         return NVK_OK;
-    DeviceScope scope(pool->device);
+    nvk::DeviceScope scope(pool->device);
     hipStream_t st = stream ? (hipStream_t)stream : pool->stream;
     if (n_heads % pool->n_kv_heads != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "n_heads=%d is not a positive multiple of n_kv_heads=%d", n_heads,
@@ -1727,7 +1710,7 @@ int nvk_prefill(nvk_pool *pool, int layer, int num_seqs, int n_heads, const floa
         return rc;
     if (total == 0)
         return NVK_OK;
-    DeviceScope  scope(pool->device);
+    nvk::DeviceScope  scope(pool->device);
     const size_t q_b   = (size_t)total * n_heads * pool->head_dim * sizeof(float);
     const size_t tab_b = (size_t)num_seqs * max_blocks * sizeof(int);
     auto         al    = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -1806,7 +1789,7 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
         if (rc != NVK_OK)
             return rc;
         nvk_pool   *mp = m->pool;
-        DeviceScope scope(mp->device);
+        nvk::DeviceScope scope(mp->device);
         if (num_tokens != m->last_tokens + 1) // not "the previous call plus one token": trust nothing staged
             std::fill(m->rows_staged.begin(), m->rows_staged.end(), 0);
         for (int i = 0; i < nblk; i++) {
@@ -1845,7 +1828,7 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
     int       rc = scratch_pool_for(block_size, n_kv_heads, head_dim, nblk, &sp);
     if (rc != NVK_OK)
         return rc;
-    DeviceScope scope(sp->device);
+    nvk::DeviceScope scope(sp->device);
     for (int i = 0; i < nblk; i++) {
         // only the rows of the block that the sequence has reached (the last block is partly filled)
         const size_t rows = (size_t)std::min(block_size, num_tokens - i * block_size) * row;
@@ -1887,7 +1870,7 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
         int         rc = mirror_for(key_cache, value_cache, kBlock, n_kv_heads, head_dim, nblk, true, &m);
         if (rc != NVK_OK)
             return rc;
-        DeviceScope scope(m->pool->device);
+        nvk::DeviceScope scope(m->pool->device);
         if (m->rows_staged.empty())
             m->rows_staged.push_back(0); // one counter: rows of the contiguous cache already on the device
         int &have = m->rows_staged[0];
@@ -1910,7 +1893,7 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
     int       rc = scratch_pool_for(kBlock, n_kv_heads, head_dim, nblk, &sp);
     if (rc != NVK_OK)
         return rc;
-    DeviceScope  scope(sp->device);
+    nvk::DeviceScope  scope(sp->device);
     const size_t bytes = (size_t)num_tokens * row * sizeof(float);
     HIP_TRY(hipMemcpyAsync(sp->k_layer(0), key_cache, bytes, hipMemcpyHostToDevice, sp->stream));
     HIP_TRY(hipMemcpyAsync(sp->v_layer(0), value_cache, bytes, hipMemcpyHostToDevice, sp->stream));
