@@ -146,6 +146,10 @@ int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_h
  *        layouts nvk_pool_rope_append_batch / _chunks take. */
 int nvk_batch_rms_norm_device(float *out_dev, const float *in_dev, const float *weight_dev, int batch_size, int dim,
                               float eps, int device, void *stream);
+/* x += addend (the residual add, include/core/model.hpp:227-228, 238-239), then out = rms_norm(x): the add that
+ * precedes every norm but a model's first, fused into it.  out must not alias x. */
+int nvk_batch_add_rms_norm_device(float *out_dev, float *x_dev, const float *addend_dev, const float *weight_dev,
+                                  int batch_size, int dim, float eps, int device, void *stream);
 int nvk_batch_matmul_device(float *out_dev, const float *in_dev, const float *weight_dev, int batch_size, int in_dim,
                             int out_dim, int device, void *stream);
 /* two products over the same activations in one launch (w_gate and w_up, include/core/model.hpp:232-233) */

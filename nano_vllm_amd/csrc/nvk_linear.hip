@@ -104,11 +104,15 @@ __device__ __forceinline__ const LinearSeg &segment_of(const LinearParams &p, in
 // out[i] = in[i] * rms * weight[i], rms = 1 / sqrtf(sum(in^2) / dim + eps)   (normalization.hpp:15-22)
 // The sum of squares is a tree over 256 threads instead of the reference's serial loop (fp32
 // association differs, inside the tolerance); the two multiplies keep the reference's order.
-__global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ out, const float *__restrict__ in,
+// ADD: first x += addend (the residual add of model.hpp:227-228 / 238-239 that precedes every norm but the first),
+// written back to `in`, then the norm of the sum.
+template <bool ADD>
+__global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ out, float *in, const float *__restrict__ addend,
                                                            const float *__restrict__ weight, int dim, float eps)
 {
     __shared__ float s_part[4];
-    const float     *x = in + (int64_t)blockIdx.x * dim;
+    float           *x = in + (int64_t)blockIdx.x * dim;
+    const float     *a = ADD ? addend + (int64_t)blockIdx.x * dim : nullptr;
     float           *y = out + (int64_t)blockIdx.x * dim;
     float            ss = 0.f;
     const int        vec = (dim % 4 == 0) ? dim / 4 : 0;
@@ -122,17 +126,30 @@ __global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ o
         held[u]     = make_float4(0.f, 0.f, 0.f, 0.f);
         if (keep && i < vec) {
             held[u] = *reinterpret_cast<const float4 *>(x + 4 * i);
+            if (ADD) {
+                const float4 b = *reinterpret_cast<const float4 *>(a + 4 * i);
+                held[u].x += b.x, held[u].y += b.y, held[u].z += b.z, held[u].w += b.w;
+                *reinterpret_cast<float4 *>(x + 4 * i) = held[u];
+            }
             ss = fmaf(held[u].x, held[u].x, ss), ss = fmaf(held[u].y, held[u].y, ss);
             ss = fmaf(held[u].z, held[u].z, ss), ss = fmaf(held[u].w, held[u].w, ss);
         }
     }
     if (!keep)
         for (int i = threadIdx.x; i < vec; i += 256) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + 4 * i);
+            float4 v = *reinterpret_cast<const float4 *>(x + 4 * i);
+            if (ADD) {
+                const float4 b = *reinterpret_cast<const float4 *>(a + 4 * i);
+                v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+                *reinterpret_cast<float4 *>(x + 4 * i) = v; // re-read below by the same thread
+            }
             ss = fmaf(v.x, v.x, ss), ss = fmaf(v.y, v.y, ss), ss = fmaf(v.z, v.z, ss), ss = fmaf(v.w, v.w, ss);
         }
-    for (int i = 4 * vec + threadIdx.x; i < dim; i += 256)
+    for (int i = 4 * vec + threadIdx.x; i < dim; i += 256) {
+        if (ADD)
+            x[i] += a[i];
         ss = fmaf(x[i], x[i], ss);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         ss += __shfl_xor(ss, o);
@@ -676,7 +693,9 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     else if (skinny) {
         // 16 x 16 tiles up to 16 rows; 32 x 32 up to 32; above, one wave carries 2 or 3 row tiles of 32 (NVK_SKINNY_TM)
         const int t  = bn;
-        const int tm = (t == 32 && NVK_SKINNY_TM && batch > 32) ? (batch + 31) / 32 : 1;
+        // (only when the column tiles alone occupy the chip: with few columns, separate workgroups per row tile are
+        //  twice as many workgroups and faster -- 2560 columns x 64 rows: 15.9 us against 24.6)
+        const int tm = (t == 32 && NVK_SKINNY_TM && batch > 32 && tiles >= 128) ? (batch + 31) / 32 : 1;
         const int bk = tm > 1 ? 32 : 64;
         p.m_tiles = tm > 1 ? 1 : (batch + t - 1) / t;
         const long long wgs = p.m_tiles == 1 ? tiles : (tiles + 7) / 8 * 8 * p.m_tiles;
@@ -750,8 +769,26 @@ int nvk_batch_rms_norm_device(float *out_dev, const float *in_dev, const float *
     if (dim % 4 == 0 && (!aligned16(out_dev) || !aligned16(in_dev) || !aligned16(weight_dev)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_rms_norm_device: pointers must be 16-byte aligned");
     nvk::DeviceScope scope(device);
-    hipLaunchKernelGGL(nvk::nvk_rms_norm_kernel, dim3((unsigned)batch_size), dim3(256), 0, (hipStream_t)stream, out_dev,
-                       in_dev, weight_dev, dim, eps);
+    hipLaunchKernelGGL(nvk::nvk_rms_norm_kernel<false>, dim3((unsigned)batch_size), dim3(256), 0, (hipStream_t)stream,
+                       out_dev, const_cast<float *>(in_dev), (const float *)nullptr, weight_dev, dim, eps);
+    HIP_TRY(hipGetLastError());
+    return NVK_OK;
+}
+
+int nvk_batch_add_rms_norm_device(float *out_dev, float *x_dev, const float *addend_dev, const float *weight_dev,
+                                  int batch_size, int dim, float eps, int device, void *stream)
+{
+    if (batch_size < 0 || dim <= 0 || !(eps >= 0.f)
+        || (batch_size > 0 && (!out_dev || !x_dev || !addend_dev || !weight_dev)) || out_dev == x_dev)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_add_rms_norm_device: bad arguments");
+    int rc = check_device(device, "nvk_batch_add_rms_norm_device");
+    if (rc != NVK_OK || batch_size == 0)
+        return rc;
+    if (dim % 4 == 0 && (!aligned16(out_dev) || !aligned16(x_dev) || !aligned16(addend_dev) || !aligned16(weight_dev)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_add_rms_norm_device: pointers must be 16-byte aligned");
+    nvk::DeviceScope scope(device);
+    hipLaunchKernelGGL(nvk::nvk_rms_norm_kernel<true>, dim3((unsigned)batch_size), dim3(256), 0, (hipStream_t)stream,
+                       out_dev, x_dev, addend_dev, weight_dev, dim, eps);
     HIP_TRY(hipGetLastError());
     return NVK_OK;
 }

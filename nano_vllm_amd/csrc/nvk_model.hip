@@ -10,8 +10,9 @@
 //
 // A step takes one token -- or a chunk of prompt tokens -- for each listed request and runs
 // model.hpp:150-247 for all their rows at once, everything on the device: embedding rows ->
-// per layer { nvk_batch_layer_hidden (rms_norm, q/k/v, RoPE, append, paged attention), wo, residual,
-// rms_norm, w_gate | w_up, SwiGLU, w_down, residual } -> final rms_norm of each request's last row ->
+// per layer { nvk_batch_layer_hidden (rms_norm, q/k/v, RoPE, append, paged attention), wo, residual + rms_norm
+// (one kernel), w_gate | w_up, SwiGLU, w_down, residual (fused into the next layer's attention norm) } ->
+// final rms_norm of each request's last row ->
 // classifier -> greedy argmax (include/core/sampler.hpp:27-29: the first maximum).
 // Host code over the public C ABI of this library plus four elementwise kernels.  No CPU path.
 
@@ -130,7 +131,7 @@ struct nvk_model
     hipStream_t        stream = nullptr; // the pool's
 
     // activations for up to max_rows rows (grown on demand) and per-request outputs
-    float *x = nullptr, *xb = nullptr, *att = nullptr, *hb = nullptr, *hb2 = nullptr;
+    float *x = nullptr, *xb = nullptr, *xn = nullptr, *att = nullptr, *hb = nullptr, *hb2 = nullptr;
     float *xl = nullptr, *logits = nullptr; // [max_seqs, dim], [max_seqs, vocab]
     int   *tokens_dev = nullptr, *last_rows_dev = nullptr, *next_dev = nullptr;
     int   *pinned = nullptr; // tokens | last rows | next tokens
@@ -151,7 +152,7 @@ void release(nvk_model *m)
         (void)nvk_pool_destroy(m->pool);
     if (m->bm)
         nvk_bm_destroy(m->bm);
-    for (float *p : {m->weights, m->x, m->xb, m->att, m->hb, m->hb2, m->xl, m->logits})
+    for (float *p : {m->weights, m->x, m->xb, m->xn, m->att, m->hb, m->hb2, m->xl, m->logits})
         if (p)
             (void)hipFree(p);
     for (int *p : {m->tokens_dev, m->last_rows_dev, m->next_dev})
@@ -167,7 +168,7 @@ int reserve_rows(nvk_model *m, int rows)
     if (rows <= m->max_rows)
         return NVK_OK;
     HIP_TRY(hipDeviceSynchronize());
-    for (float **p : {&m->x, &m->xb, &m->att, &m->hb, &m->hb2})
+    for (float **p : {&m->x, &m->xb, &m->xn, &m->att, &m->hb, &m->hb2})
         if (*p) {
             (void)hipFree(*p);
             *p = nullptr;
@@ -180,6 +181,7 @@ int reserve_rows(nvk_model *m, int rows)
     const size_t r = (size_t)std::max(rows, m->max_seqs);
     HIP_TRY(hipMalloc((void **)&m->x, r * m->dim * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&m->xb, r * m->dim * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&m->xn, r * m->dim * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&m->att, r * (size_t)m->n_heads * m->head_dim * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&m->hb, r * m->hidden_dim * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&m->hb2, r * m->hidden_dim * sizeof(float)));
@@ -425,25 +427,33 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
         return fail_step(nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: staging the tokens failed"));
     hipLaunchKernelGGL(nvk_embed_kernel, dim3((unsigned)R), dim3(64), 0, st, m->x, m->tok_emb, m->tokens_dev, D, V);
     const unsigned ew_blocks = 1024;
+    // The residual adds (model.hpp:227-228, 238-239) ride in the norm that follows them: after layer l's w_down the sum
+    // x += xb and layer l + 1's attention norm are one kernel (its output feeds nvk_batch_layer_hidden already
+    // normalised); only the last layer's add stands alone.
+    const float *attn_in = m->x; // layer 0 normalises x itself
     for (int l = 0; l < m->n_layers && rc == NVK_OK; l++) {
         const LayerWeights &w = m->layers[(size_t)l];
-        rc = nvk_batch_layer_hidden(m->batch, l, m->x, D, w.rms_att, w.wq, w.wk, w.wv, m->rms_eps, m->att, m->rope_theta,
-                                    (void *)st); // model.hpp:161-221
+        rc = nvk_batch_layer_hidden(m->batch, l, attn_in, D, l == 0 ? w.rms_att : nullptr, w.wq, w.wk, w.wv, m->rms_eps,
+                                    m->att, m->rope_theta, (void *)st); // model.hpp:161-221
         if (rc == NVK_OK)
             rc = nvk_batch_matmul_device(m->xb, m->att, w.wo, R, QD, D, m->device, (void *)st); // :224
-        if (rc != NVK_OK)
-            break;
-        hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4); // :227
-        rc = nvk_batch_rms_norm_device(m->xb, m->x, w.rms_ffn, R, D, m->rms_eps, m->device, (void *)st);             // :231
+        if (rc == NVK_OK) // :227-231: x += xb; hb2 <- rms_norm(x, rms_ffn)  
+            rc = nvk_batch_add_rms_norm_device(m->xn, m->x, m->xb, w.rms_ffn, R, D, m->rms_eps, m->device, (void *)st);
         if (rc == NVK_OK)
-            rc = nvk_batch_matmul2_device(m->hb, m->hb2, m->xb, w.w_gate, w.w_up, R, D, Hd, Hd, m->device, (void *)st); // :232-233
+            rc = nvk_batch_matmul2_device(m->hb, m->hb2, m->xn, w.w_gate, w.w_up, R, D, Hd, Hd, m->device, (void *)st); // :232-233
         if (rc != NVK_OK)
             break;
         hipLaunchKernelGGL(nvk_swiglu_kernel, dim3(ew_blocks), dim3(256), 0, st, m->hb, m->hb2, (int64_t)R * Hd);   // :234
         rc = nvk_batch_matmul_device(m->xb, m->hb, w.w_down, R, Hd, D, m->device, (void *)st);                      // :235
         if (rc != NVK_OK)
             break;
-        hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4); // :238
+        if (l + 1 < m->n_layers) { // :238-239 + the next layer's :161
+            rc = nvk_batch_add_rms_norm_device(m->xn, m->x, m->xb, m->layers[(size_t)l + 1].rms_att, R, D, m->rms_eps,
+                                               m->device, (void *)st);
+            attn_in = m->xn;
+        }
+        else
+            hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4);
     }
     if (rc != NVK_OK)
         return fail_step(rc);

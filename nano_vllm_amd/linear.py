@@ -20,6 +20,14 @@ def batch_rms_norm_device(out_dev, in_dev, weight_dev, batch_size: int, dim: int
                                                     int(batch_size), int(dim), float(eps), int(device), _devptr(stream)))
 
 
+def batch_add_rms_norm_device(out_dev, x_dev, addend_dev, weight_dev, batch_size: int, dim: int, eps: float = RMS_EPS,
+                              device: int = 0, stream=None) -> None:
+    """x += addend (the residual add, model.hpp:227-228), then out = rms_norm(x), in one kernel."""
+    _capi.check(_capi.lib.nvk_batch_add_rms_norm_device(_devptr(out_dev), _devptr(x_dev), _devptr(addend_dev),
+                                                        _devptr(weight_dev), int(batch_size), int(dim), float(eps),
+                                                        int(device), _devptr(stream)))
+
+
 def batch_matmul_device(out_dev, in_dev, weight_dev, batch_size: int, in_dim: int, out_dim: int, device: int = 0,
                         stream=None) -> None:
     """out[b][i] = dot(in[b], weight[i]), weight [out_dim, in_dim] (BatchOps::batch_matmul)."""

@@ -70,6 +70,25 @@ def test_rms_norm_rows_and_in_place(nv, DA):
         assert np.array_equal(dx.numpy(), out.numpy())
 
 
+def test_residual_add_fused_into_the_norm(nv, DA):
+    """nvk_batch_add_rms_norm_device: x += addend (bit-exact: one fp32 add per element, model.hpp:227-228), then the norm
+    of the sum -- the same bits as the add followed by nvk_batch_rms_norm_device."""
+    for seed, (B, D) in enumerate([(1, 288), (5, 4096), (3, 9000), (2, 6)]):
+        x = uniform(1200 + seed, 0, B * D).reshape(B, D)
+        y = uniform(1210 + seed, 0, B * D).reshape(B, D) * np.float32(0.3)
+        g = uniform(1220 + seed, 0, D) + np.float32(1.5)
+        dx, out = DA(x), DA(np.zeros_like(x))
+        nv.batch_add_rms_norm_device(out, dx, DA(y), DA(g), B, D)
+        assert np.array_equal(dx.numpy(), x + y)
+        want = ol.batch_rms_norm(ol.ORACLE.oracle_batch_rms_norm, x + y, g)
+        assert close(out.numpy(), want)
+        ref = DA(np.zeros_like(x))
+        nv.batch_rms_norm_device(ref, DA(x + y), DA(g), B, D)
+        assert np.array_equal(out.numpy(), ref.numpy())
+    with pytest.raises(nv.NvkError):
+        nv.batch_add_rms_norm_device(dx, dx, dx, dx, 1, 4)  # out must not alias x
+
+
 @pytest.mark.parametrize("B,D,N", [(1, 4096, 4096), (4, 288, 288), (32, 1024, 100), (33, 1024, 100), (17, 100, 33),
                                     (128, 512, 384), (129, 260, 130), (300, 64, 1), (2, 4, 3)])
 def test_matmul_shapes_against_the_checker(B, D, N, nv, DA):
