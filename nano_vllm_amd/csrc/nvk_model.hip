@@ -80,31 +80,45 @@ __global__ void nvk_take_rows_kernel(float *__restrict__ dst, const float *__res
 }
 
 // next[r] = index of the first maximum of logits[r]  (Sampler, include/core/sampler.hpp:27-29: std::max_element)
-__global__ void __launch_bounds__(256) nvk_argmax_kernel(int *__restrict__ next, const float *__restrict__ logits, int vocab)
+// One workgroup of 1024 threads per row, float4 loads (a 32000-entry row is 8 loads per thread in flight at once;
+// with 256 scalar-loading threads the kernel took 41 us of pure latency).
+constexpr int kArgmaxThreads = 1024;
+__device__ __forceinline__ void argmax_take(float v, int i, float &best, int &at)
 {
-    __shared__ float s_v[256];
-    __shared__ int   s_i[256];
-    const float     *row = logits + (int64_t)blockIdx.x * vocab;
+    if (v > best || (v == best && i < at)) // NaNs never win, like operator< in std::max_element
+        best = v, at = i;
+}
+__global__ void __launch_bounds__(kArgmaxThreads) nvk_argmax_kernel(int *__restrict__ next, const float *__restrict__ logits,
+                                                                    int vocab)
+{
+    __shared__ float s_v[kArgmaxThreads / 64];
+    __shared__ int   s_i[kArgmaxThreads / 64];
+    const float     *row  = logits + (int64_t)blockIdx.x * vocab;
     float            best = -INFINITY;
     int              at   = 0x7fffffff;
-    for (int i = threadIdx.x; i < vocab; i += 256) {
-        const float v = row[i];
-        if (v > best || (v == best && i < at) || at == 0x7fffffff)
-            best = v, at = i;
+    const bool       vec  = vocab % 4 == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    const int        n4   = vec ? vocab / 4 : 0;
+    for (int i = threadIdx.x; i < n4; i += kArgmaxThreads) {
+        const float4 v = reinterpret_cast<const float4 *>(row)[i];
+        argmax_take(v.x, 4 * i, best, at), argmax_take(v.y, 4 * i + 1, best, at);
+        argmax_take(v.z, 4 * i + 2, best, at), argmax_take(v.w, 4 * i + 3, best, at);
     }
-    s_v[threadIdx.x] = best, s_i[threadIdx.x] = at;
+    for (int i = 4 * n4 + threadIdx.x; i < vocab; i += kArgmaxThreads)
+        argmax_take(row[i], i, best, at);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v = __shfl_xor(best, o);
+        const int   i = __shfl_xor(at, o);
+        argmax_take(v, i, best, at);
+    }
+    if ((threadIdx.x & 63) == 0)
+        s_v[threadIdx.x >> 6] = best, s_i[threadIdx.x >> 6] = at;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const float v = s_v[threadIdx.x + o];
-            const int   i = s_i[threadIdx.x + o];
-            if (v > s_v[threadIdx.x] || (v == s_v[threadIdx.x] && i < s_i[threadIdx.x]))
-                s_v[threadIdx.x] = v, s_i[threadIdx.x] = i;
-        }
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kArgmaxThreads / 64; w++)
+            argmax_take(s_v[w], s_i[w], best, at);
+        next[blockIdx.x] = at == 0x7fffffff ? 0 : at; // a row of -inf / NaN only: the first element, as max_element
     }
-    if (threadIdx.x == 0)
-        next[blockIdx.x] = s_i[0] == 0x7fffffff ? 0 : s_i[0];
 }
 
 struct LayerWeights
@@ -464,7 +478,7 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
         rc = nvk_batch_matmul_device(m->logits, m->xl, m->lm_head, n, D, V, m->device, (void *)st);
     if (rc != NVK_OK)
         return fail_step(rc);
-    hipLaunchKernelGGL(nvk_argmax_kernel, dim3((unsigned)n), dim3(256), 0, st, m->next_dev, m->logits, V);
+    hipLaunchKernelGGL(nvk_argmax_kernel, dim3((unsigned)n), dim3(kArgmaxThreads), 0, st, m->next_dev, m->logits, V);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpyAsync(h_next, m->next_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st);
