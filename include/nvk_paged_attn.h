@@ -78,6 +78,8 @@ int nvk_pool_geometry(const nvk_pool *pool, int *out6);
 int nvk_pool_layer_ptrs(const nvk_pool *pool, int layer, void **k_dev, void **v_dev);
 /* the pool's own HIP stream (hipStream_t) */
 int nvk_pool_stream(const nvk_pool *pool, void **stream);
+/* Counts the (re)allocations of the split-K workspace: launches recorded in a hipGraph hold its address. */
+long long nvk_pool_workspace_generation(const nvk_pool *pool);
 int nvk_pool_synchronize(nvk_pool *pool);
 
 /* KV append of one token row, host pointers.
@@ -346,6 +348,11 @@ int nvk_batch_layer_hidden(nvk_batch *batch, int layer, const float *x_dev, int 
                            const float *wq_dev, const float *wk_dev, const float *wv_dev, float rms_eps, float *out_dev,
                            float rope_theta, void *stream);
 int nvk_batch_end_step(nvk_batch *batch);
+/* For callers that capture a step's nvk_batch_layer / nvk_batch_layer_hidden calls in a hipGraph and replay it on later
+ * steps: out8 describes everything the captured launches bake in besides the caller's own pointers (rows, kind of
+ * step, the plan's launch shape, the addresses of the library's scratch).  A graph captured under one signature may
+ * be replayed in any later step whose signature is equal (pure decode steps keep theirs for up to 256 steps). */
+int nvk_batch_graph_signature(const nvk_batch *batch, long long *out8);
 /* Abandons the step in flight (a later call of the step failed): no request advances; blocks drawn for the step
  * stay with their requests. */
 int nvk_batch_abort_step(nvk_batch *batch);
@@ -385,6 +392,9 @@ int nvk_model_add_request(nvk_model *model, int request_id);
 int nvk_model_finish_request(nvk_model *model, int request_id); /* frees its KV blocks */
 int nvk_model_request_len(const nvk_model *model, int request_id);
 int nvk_model_free_blocks(const nvk_model *model);
+/* Pure decode steps replay a hipGraph of their ~12 launches per layer (captured again whenever the batch, the launch
+ * shape or a scratch address changes); on by default, results are the same bits either way.  0 switches it off. */
+int nvk_model_use_graphs(nvk_model *model, int on);
 /* One model step: request i takes the next chunk_lens[i] >= 1 tokens of `tokens` (packed in list order; a prompt
  * chunk, or 1 = decode).  next_tokens [n] (host, may be NULL) = greedy argmax after each request's last token;
  * logits [n, vocab_size] (host, may be NULL) = the classifier's output for those rows.  Synchronous. */

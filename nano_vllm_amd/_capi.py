@@ -118,6 +118,8 @@ SIGNATURES = {
     "nvk_batch_begin_step_chunks": (C.c_int, [_vp, _i, _i, C.c_int, C.c_int, _vp]),
     "nvk_batch_step_rows": (C.c_int, [_vp]),
     "nvk_batch_abort_step": (C.c_int, [_vp]),
+    "nvk_batch_graph_signature": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
+    "nvk_pool_workspace_generation": (C.c_longlong, [_vp]),
     "nvk_tokenizer_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "nvk_tokenizer_destroy": (None, [_vp]),
     "nvk_tokenizer_vocab_size": (C.c_int, [_vp]),
@@ -131,6 +133,7 @@ SIGNATURES = {
     "nvk_model_finish_request": (C.c_int, [_vp, C.c_int]),
     "nvk_model_request_len": (C.c_int, [_vp, C.c_int]),
     "nvk_model_free_blocks": (C.c_int, [_vp]),
+    "nvk_model_use_graphs": (C.c_int, [_vp, C.c_int]),
     "nvk_model_step_chunks": (C.c_int, [_vp, _i, _i, _i, C.c_int, _i, _f]),
     "nvk_model_step": (C.c_int, [_vp, _i, _i, C.c_int, _i, _f]),
     "nvk_model_forward": (C.c_int, [_vp, C.c_int, C.c_int, _f]),

@@ -343,6 +343,9 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
         }
         max_ctx = std::max(max_ctx, s.len + 1);
     }
+    // The launch shape (chunking, grid bound) is derived from max_ctx: keep it the same for 256 steps at a time, so a
+    // caller that captured the step's layer calls in a hipGraph (nvk_batch_graph_signature) can replay it that long.
+    max_ctx = (int)std::min<long long>(((long long)max_ctx + 255) / 256 * 256, (long long)b->max_blocks * b->block_size);
 
     // 3. bring the step's tables / positions / context lengths to the device
     if (n > 0) {
@@ -601,6 +604,24 @@ int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim,
     if (rc != NVK_OK)
         return rc;
     return nvk_batch_layer(b, layer, b->h_q, b->h_k, b->h_v, out_dev, rope_theta, (void *)st);
+}
+
+int nvk_batch_graph_signature(const nvk_batch *b, long long *out8)
+{
+    if (!b || !out8 || !b->in_step)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_graph_signature: no step in flight");
+    int info[4] = {0, 0, 0, 0};
+    if (!b->step_ids.empty() && !(b->chunked && b->n_decode == 0)) {
+        int rc = nvk_plan_info(b->plan, info);
+        if (rc != NVK_OK)
+            return rc;
+    }
+    out8[0] = (long long)b->step_ids.size();
+    out8[1] = b->chunked ? 1 : 0;
+    out8[2] = info[0], out8[3] = info[1], out8[4] = info[2], out8[5] = info[3];
+    out8[6] = nvk_pool_workspace_generation(b->pool);
+    out8[7] = (long long)(intptr_t)b->h_q ^ ((long long)b->n_heads << 48);
+    return NVK_OK;
 }
 
 int nvk_batch_abort_step(nvk_batch *b)

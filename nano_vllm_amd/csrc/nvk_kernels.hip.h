@@ -662,6 +662,86 @@ __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict_
         make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
+// ---- split-K merge for few rows and many chunks ------------------------------
+// nvk_merge_kernel walks a row's chunks one after the other: with a handful of sequences cut into dozens of short
+// chunks (the shape AUTO picks to occupy the chip with one request) that walk is a chain of dependent-latency loads
+// on a nearly empty GPU.  Here one workgroup owns one (sequence, q-head): its 256 threads take one chunk's (m, l)
+// each, agree on the maximum and the denominator through two block reductions, then split into 256 / (head_dim / 4)
+// groups that each accumulate every groups-th chunk's partial row; the groups meet in LDS and are added in group
+// order.  Needs max_chunks <= 256.  Same (m, l, o) convention as nvk_merge_kernel; the order of the sums differs.
+constexpr int kMergeWideMaxChunks = 256;
+
+__global__ void __launch_bounds__(256) nvk_merge_wide_kernel(const float *__restrict__ ws_o,
+                                                             const float *__restrict__ ws_ml,
+                                                             const int *__restrict__ seq_chunks, float *__restrict__ out,
+                                                             int n_heads, int head_dim, int max_chunks)
+{
+    __shared__ float  s_f[kMergeWideMaxChunks];
+    __shared__ float  s_red[8];
+    __shared__ float4 s_acc[256];
+    const int seq = blockIdx.x, head = blockIdx.y;
+    const int nch = min(seq_chunks[seq], max_chunks); // uniform over the workgroup
+    if (nch <= 1)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = (int64_t)seq * max_chunks * n_heads + head; // chunk c's slab row = row0 + c * n_heads
+
+    float2 s = make_float2(kRefMaxFloorLog2, 0.f);
+    if (tid < nch)
+        s = *reinterpret_cast<const float2 *>(ws_ml + (row0 + (int64_t)tid * n_heads) * 2);
+    float top = s.x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+        top = fmaxf(top, __shfl_xor(top, d));
+    if (lane == 0)
+        s_red[wave] = top;
+    __syncthreads();
+    top = fmaxf(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), kRefMaxFloorLog2);
+    const float f = tid < nch ? fast_exp2(s.x - top) : 0.f;
+    s_f[tid]      = f;
+    float denom   = s.y * f;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+        denom += __shfl_xor(denom, d);
+    if (lane == 0)
+        s_red[4 + wave] = denom;
+    __syncthreads();
+    denom = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+
+    const int vec_row = head_dim >> 2, groups = 256 / vec_row;
+    const int g = tid / vec_row, vec = tid - g * vec_row;
+    float4    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < groups) {
+        const float *po = ws_o + row0 * head_dim + 4 * vec;
+        const int64_t cs = (int64_t)n_heads * head_dim; // floats between chunks
+        int c = g;
+        for (; c + groups < nch; c += 2 * groups) { // two independent loads in flight
+            const float4 a = *reinterpret_cast<const float4 *>(po + c * cs);
+            const float4 b = *reinterpret_cast<const float4 *>(po + (c + groups) * cs);
+            const float  fa = s_f[c], fb = s_f[c + groups];
+            acc.x = fmaf(a.x, fa, acc.x), acc.y = fmaf(a.y, fa, acc.y), acc.z = fmaf(a.z, fa, acc.z), acc.w = fmaf(a.w, fa, acc.w);
+            acc.x = fmaf(b.x, fb, acc.x), acc.y = fmaf(b.y, fb, acc.y), acc.z = fmaf(b.z, fb, acc.z), acc.w = fmaf(b.w, fb, acc.w);
+        }
+        if (c < nch) {
+            const float4 a = *reinterpret_cast<const float4 *>(po + c * cs);
+            const float  fa = s_f[c];
+            acc.x = fmaf(a.x, fa, acc.x), acc.y = fmaf(a.y, fa, acc.y), acc.z = fmaf(a.z, fa, acc.z), acc.w = fmaf(a.w, fa, acc.w);
+        }
+    }
+    s_acc[tid] = acc;
+    __syncthreads();
+    if (tid < vec_row) {
+        float4 sum = s_acc[tid];
+        for (int k = 1; k < groups; k++) {
+            const float4 a = s_acc[k * vec_row + tid];
+            sum.x += a.x, sum.y += a.y, sum.z += a.z, sum.w += a.w;
+        }
+        const float inv = 1.0f / denom;
+        *reinterpret_cast<float4 *>(out + ((int64_t)seq * n_heads + head) * head_dim + 4 * tid) =
+            make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+    }
+}
+
 // ---- KV gather on its own (addressing check) --------------------------------
 // grid.x = tokens; copies K and V rows of one kv-head to [num_tokens, head_dim].
 __global__ void nvk_gather_kernel(const float *__restrict__ k_layer, const float *__restrict__ v_layer,

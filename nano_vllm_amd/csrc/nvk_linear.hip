@@ -43,7 +43,16 @@
 #define NVK_GEMM_FORCE_TILE 0 // tuning: 128 or 64 pins the tiled kernel's tile, 0 = by workgroup count
 #endif
 #ifndef NVK_GEMV_COLS
-#define NVK_GEMV_COLS 16 // weight rows (output columns) per GEMV workgroup: 8 or 16
+#define NVK_GEMV_COLS 4 // weight rows (output columns) per GEMV workgroup: 4, 8 or 16.  Measured per shape
+                        // (tools/gemv_sweep.sh, profiles/r01_qkv_projection.log): 4 is the fastest for one row at every
+                        // size (2048 x 2048 is 512 workgroups instead of 128, and fewer registers let more of them
+                        // share a CU), and for two rows up to a few thousand columns
+#endif
+#ifndef NVK_GEMV2_WIDE_COLS
+#define NVK_GEMV2_WIDE_COLS 16 // two rows and more than NVK_GEMV2_WIDE_FROM columns: 16 per workgroup
+#endif
+#ifndef NVK_GEMV2_WIDE_FROM
+#define NVK_GEMV2_WIDE_FROM 4096
 #endif
 #ifndef NVK_GEMV_DEPTH
 #define NVK_GEMV_DEPTH 2 // steps of weight loads a GEMV wave keeps in flight
@@ -511,9 +520,9 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
 
 // ---- C = A . W^T, at most 8 rows: the reference's own case (one token: Ops::matmul is a GEMV) -------
 // HBM-bound: every weight byte is read once and multiplied on the vector ALUs (an MFMA tile padded to 32
-// rows would cost as much time as the stream itself).  One workgroup = 16 output columns (16 weight rows),
-// 8 waves dealing the contraction round-robin in steps of 64; a lane holds a float4 of four weight rows
-// per step (256 contiguous bytes per row and instruction), two steps in flight, and the matching float4
+// rows would cost as much time as the stream itself).  One workgroup = kGemvCols output columns (weight rows:
+// 4, or 16 for two rows of a wide output), 8 waves dealing the contraction round-robin in steps of 64; a lane holds
+// a float4 of kGemvCols / 4 weight rows per step (256 contiguous bytes per row and instruction), two steps in flight, and the matching float4
 // of every activation row (L2-resident).  Per lane partial sums -> DPP row sum over the 16 lanes of a
 // weight row -> the eight waves meet in LDS.  An output's summation order depends on k only.
 constexpr int kGemvWaves = 8, kGemvBK = 64;
@@ -662,8 +671,13 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         if (NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
             bm = bn = 64;
     }
-    else
-        bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
+    else {
+        long long cols = 0;
+        for (int s = 0; s < nseg; s++)
+            cols += n[s];
+        const int gemv_cols = batch == 2 && cols > NVK_GEMV2_WIDE_FROM ? NVK_GEMV2_WIDE_COLS : NVK_GEMV_COLS;
+        bn = gemv ? (batch <= 2 ? gemv_cols : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
+    }
     long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
@@ -683,8 +697,10 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         const dim3 grid((unsigned)tiles), block(64 * nvk::kGemvWaves);
         if (batch == 1)
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
-        else if (batch == 2)
+        else if (batch == 2 && bn == NVK_GEMV_COLS)
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
+        else if (batch == 2)
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV2_WIDE_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
 #if NVK_GEMV_MAX_ROWS > 2
         else
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<4, 32, 2>), grid, block, 0, st, p);

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -150,6 +151,15 @@ struct nvk_model
     int   *tokens_dev = nullptr, *last_rows_dev = nullptr, *next_dev = nullptr;
     int   *pinned = nullptr; // tokens | last rows | next tokens
     size_t pinned_ints = 0;
+
+    // The body of a pure decode step (embedding .. sampler, ~12 launches per layer) captured as a hipGraph and replayed
+    // while nothing it bakes in has changed: with few requests a step is hundreds of short dependent kernels and
+    // the launch gaps, not the kernels, set its time.
+    bool            use_graphs = true;
+    int             graph_failures = 0;
+    hipGraphExec_t  graph_exec = nullptr;
+    long long       graph_sig[9] = {0};
+    long long       graph_seen[9] = {0}; // the last pure decode step's shape, recorded or not
 };
 
 namespace {
@@ -160,6 +170,8 @@ void release(nvk_model *m)
         return;
     nvk::DeviceScope scope(m->device);
     (void)hipDeviceSynchronize();
+    if (m->graph_exec)
+        (void)hipGraphExecDestroy(m->graph_exec);
     if (m->batch)
         (void)nvk_batch_destroy(m->batch);
     if (m->pool)
@@ -182,6 +194,10 @@ int reserve_rows(nvk_model *m, int rows)
     if (rows <= m->max_rows)
         return NVK_OK;
     HIP_TRY(hipDeviceSynchronize());
+    if (m->graph_exec) { // it holds the old buffers' addresses
+        (void)hipGraphExecDestroy(m->graph_exec);
+        m->graph_exec = nullptr;
+    }
     for (float **p : {&m->x, &m->xb, &m->xn, &m->att, &m->hb, &m->hb2})
         if (*p) {
             (void)hipFree(*p);
@@ -385,6 +401,21 @@ int nvk_model_request_len(const nvk_model *m, int request_id)
     return nvk_batch_request_len(m->batch, request_id);
 }
 
+int nvk_model_use_graphs(nvk_model *m, int on)
+{
+    if (!m)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_use_graphs: null model");
+    m->use_graphs     = on != 0;
+    m->graph_failures = 0;
+    if (!on && m->graph_exec) {
+        nvk::DeviceScope scope(m->device);
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipGraphExecDestroy(m->graph_exec);
+        m->graph_exec = nullptr;
+    }
+    return NVK_OK;
+}
+
 int nvk_model_free_blocks(const nvk_model *m) { return m ? nvk_bm_num_free_blocks(m->bm) : 0; }
 
 int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk_lens, const int *tokens, int n,
@@ -436,53 +467,122 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
         (void)nvk_batch_abort_step(m->batch);
         return code;
     };
-    if (hipMemcpyAsync(m->tokens_dev, h_tok, (size_t)R * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess
-        || hipMemcpyAsync(m->last_rows_dev, h_last, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
-        return fail_step(nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: staging the tokens failed"));
-    hipLaunchKernelGGL(nvk_embed_kernel, dim3((unsigned)R), dim3(64), 0, st, m->x, m->tok_emb, m->tokens_dev, D, V);
-    const unsigned ew_blocks = 1024;
-    // The residual adds (model.hpp:227-228, 238-239) ride in the norm that follows them: after layer l's w_down the sum
-    // x += xb and layer l + 1's attention norm are one kernel (its output feeds nvk_batch_layer_hidden already
-    // normalised); only the last layer's add stands alone.
-    const float *attn_in = m->x; // layer 0 normalises x itself
-    for (int l = 0; l < m->n_layers && rc == NVK_OK; l++) {
-        const LayerWeights &w = m->layers[(size_t)l];
-        rc = nvk_batch_layer_hidden(m->batch, l, attn_in, D, l == 0 ? w.rms_att : nullptr, w.wq, w.wk, w.wv, m->rms_eps,
-                                    m->att, m->rope_theta, (void *)st); // model.hpp:161-221
-        if (rc == NVK_OK)
-            rc = nvk_batch_matmul_device(m->xb, m->att, w.wo, R, QD, D, m->device, (void *)st); // :224
-        if (rc == NVK_OK) // :227-231: x += xb; hb2 <- rms_norm(x, rms_ffn)  
-            rc = nvk_batch_add_rms_norm_device(m->xn, m->x, m->xb, w.rms_ffn, R, D, m->rms_eps, m->device, (void *)st);
-        if (rc == NVK_OK)
-            rc = nvk_batch_matmul2_device(m->hb, m->hb2, m->xn, w.w_gate, w.w_up, R, D, Hd, Hd, m->device, (void *)st); // :232-233
-        if (rc != NVK_OK)
-            break;
-        hipLaunchKernelGGL(nvk_swiglu_kernel, dim3(ew_blocks), dim3(256), 0, st, m->hb, m->hb2, (int64_t)R * Hd);   // :234
-        rc = nvk_batch_matmul_device(m->xb, m->hb, w.w_down, R, Hd, D, m->device, (void *)st);                      // :235
-        if (rc != NVK_OK)
-            break;
-        if (l + 1 < m->n_layers) { // :238-239 + the next layer's :161
-            rc = nvk_batch_add_rms_norm_device(m->xn, m->x, m->xb, m->layers[(size_t)l + 1].rms_att, R, D, m->rms_eps,
-                                               m->device, (void *)st);
-            attn_in = m->xn;
+    // everything between the batch's bookkeeping and the host's wait: tokens in, embedding .. sampler, next tokens out
+    auto enqueue_body = [&]() -> int {
+        hipError_t e1 = hipMemcpyAsync(m->tokens_dev, h_tok, (size_t)R * sizeof(int), hipMemcpyHostToDevice, st);
+        if (e1 == hipSuccess)
+            e1 = hipMemcpyAsync(m->last_rows_dev, h_last, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st);
+        if (e1 != hipSuccess)
+            return nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: staging the tokens failed: %s", hipGetErrorString(e1));
+        hipLaunchKernelGGL(nvk_embed_kernel, dim3((unsigned)R), dim3(64), 0, st, m->x, m->tok_emb, m->tokens_dev, D, V);
+        const unsigned ew_blocks = 1024;
+        // The residual adds (model.hpp:227-228, 238-239) ride in the norm that follows them: after layer l's w_down the
+        // sum x += xb and layer l + 1's attention norm are one kernel (its output feeds nvk_batch_layer_hidden already
+        // normalised); only the last layer's add stands alone.
+        const float *attn_in = m->x; // layer 0 normalises x itself
+        int          r2      = NVK_OK;
+        for (int l = 0; l < m->n_layers && r2 == NVK_OK; l++) {
+            const LayerWeights &w = m->layers[(size_t)l];
+            r2 = nvk_batch_layer_hidden(m->batch, l, attn_in, D, l == 0 ? w.rms_att : nullptr, w.wq, w.wk, w.wv, m->rms_eps,
+                                        m->att, m->rope_theta, (void *)st); // model.hpp:161-221
+            if (r2 == NVK_OK)
+                r2 = nvk_batch_matmul_device(m->xb, m->att, w.wo, R, QD, D, m->device, (void *)st); // :224
+            if (r2 == NVK_OK) // :227-231: x += xb; xn = rms_norm(x, rms_ffn)
+                r2 = nvk_batch_add_rms_norm_device(m->xn, m->x, m->xb, w.rms_ffn, R, D, m->rms_eps, m->device, (void *)st);
+            if (r2 == NVK_OK) // :232-233
+                r2 = nvk_batch_matmul2_device(m->hb, m->hb2, m->xn, w.w_gate, w.w_up, R, D, Hd, Hd, m->device, (void *)st);
+            if (r2 != NVK_OK)
+                break;
+            hipLaunchKernelGGL(nvk_swiglu_kernel, dim3(ew_blocks), dim3(256), 0, st, m->hb, m->hb2, (int64_t)R * Hd); // :234
+            r2 = nvk_batch_matmul_device(m->xb, m->hb, w.w_down, R, Hd, D, m->device, (void *)st);                    // :235
+            if (r2 != NVK_OK)
+                break;
+            if (l + 1 < m->n_layers) { // :238-239 + the next layer's :161
+                r2 = nvk_batch_add_rms_norm_device(m->xn, m->x, m->xb, m->layers[(size_t)l + 1].rms_att, R, D, m->rms_eps,
+                                                   m->device, (void *)st);
+                attn_in = m->xn;
+            }
+            else
+                hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4);
         }
-        else
-            hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4);
+        if (r2 != NVK_OK)
+            return r2;
+        // final norm + classifier for each request's last row only (model.hpp:243-246), then the greedy sampler
+        hipLaunchKernelGGL(nvk_take_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, m->xl, m->x, m->last_rows_dev, D);
+        r2 = nvk_batch_rms_norm_device(m->xl, m->xl, m->rms_final, n, D, m->rms_eps, m->device, (void *)st);
+        if (r2 == NVK_OK)
+            r2 = nvk_batch_matmul_device(m->logits, m->xl, m->lm_head, n, D, V, m->device, (void *)st);
+        if (r2 != NVK_OK)
+            return r2;
+        hipLaunchKernelGGL(nvk_argmax_kernel, dim3((unsigned)n), dim3(kArgmaxThreads), 0, st, m->next_dev, m->logits, V);
+        hipError_t e2 = hipGetLastError();
+        if (e2 == hipSuccess)
+            e2 = hipMemcpyAsync(h_next, m->next_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e2 != hipSuccess)
+            return nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: %s", hipGetErrorString(e2));
+        return NVK_OK;
+    };
+
+    bool replayed = false;
+    if (m->use_graphs && R == n) { // a pure decode step
+        long long sig[9];
+        sig[8] = R;
+        if (nvk_batch_graph_signature(m->batch, sig) == NVK_OK) {
+            const bool stale = !m->graph_exec || std::memcmp(sig, m->graph_sig, sizeof sig) != 0;
+            if (stale && m->graph_exec) {
+                (void)hipGraphExecDestroy(m->graph_exec);
+                m->graph_exec = nullptr;
+            }
+            // A shape is recorded the second time it is seen in a row: its first step runs directly, so that the
+            // first-use allocations inside the entry points (scratch rows, the rope table) happen outside a capture.
+            const bool seen = std::memcmp(sig, m->graph_seen, sizeof sig) == 0;
+            std::memcpy(m->graph_seen, sig, sizeof sig);
+            if (stale && seen) {
+                // record the body (nothing runs while capturing); any refusal -- a first-use allocation inside an entry
+                // point, say -- ends the capture and this step runs directly
+                hipGraph_t graph = nullptr;
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int  rb = enqueue_body();
+                    hipError_t ec = hipStreamEndCapture(st, &graph);
+                    if (rb == NVK_OK && ec == hipSuccess && graph
+                        && hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess)
+                    {
+                        std::memcpy(m->graph_sig, sig, sizeof sig);
+                        if (std::getenv("NVK_GRAPH_DEBUG"))
+                            std::fprintf(stderr, "nvk_model: recorded a %d-request decode step\n", n);
+                    }
+                    else {
+                        if (std::getenv("NVK_GRAPH_DEBUG"))
+                            std::fprintf(stderr, "nvk_model: capture refused (body %d: %s; end %s)\n", rb,
+                                         rb == NVK_OK ? "ok" : nvk_last_error(), hipGetErrorString(ec));
+                        m->graph_exec = nullptr;
+                        (void)hipGetLastError(); // clear the sticky capture error
+                        if (++m->graph_failures >= 4)
+                            m->use_graphs = false;
+                    }
+                    if (graph)
+                        (void)hipGraphDestroy(graph);
+                }
+            }
+            if (m->graph_exec) {
+                if (hipGraphLaunch(m->graph_exec, st) == hipSuccess)
+                    replayed = true;
+                else {
+                    (void)hipGetLastError();
+                    (void)hipGraphExecDestroy(m->graph_exec);
+                    m->graph_exec = nullptr;
+                    m->use_graphs = false;
+                }
+            }
+        }
     }
-    if (rc != NVK_OK)
-        return fail_step(rc);
-    // final norm + classifier for each request's last row only (model.hpp:243-246), then the greedy sampler
-    hipLaunchKernelGGL(nvk_take_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, m->xl, m->x, m->last_rows_dev, D);
-    rc = nvk_batch_rms_norm_device(m->xl, m->xl, m->rms_final, n, D, m->rms_eps, m->device, (void *)st);
-    if (rc == NVK_OK)
-        rc = nvk_batch_matmul_device(m->logits, m->xl, m->lm_head, n, D, V, m->device, (void *)st);
-    if (rc != NVK_OK)
-        return fail_step(rc);
-    hipLaunchKernelGGL(nvk_argmax_kernel, dim3((unsigned)n), dim3(kArgmaxThreads), 0, st, m->next_dev, m->logits, V);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(h_next, m->next_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && logits)
+    if (!replayed) {
+        rc = enqueue_body();
+        if (rc != NVK_OK)
+            return fail_step(rc);
+    }
+    hipError_t e = hipSuccess;
+    if (logits)
         e = hipMemcpyAsync(logits, m->logits, (size_t)n * V * sizeof(float), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);

@@ -29,6 +29,12 @@
 #ifndef NVK_AUTO_MIN_CHUNK
 #define NVK_AUTO_MIN_CHUNK 128 // shortest chunk NVK_DECODE_AUTO picks (a multiple of every kernel step: 4..16 tokens)
 #endif
+#ifndef NVK_AUTO_MIN_CHUNK_WIDE
+#define NVK_AUTO_MIN_CHUNK_WIDE 32 // the same when the merge is nvk_merge_wide_kernel (few rows; tools/merge_sweep.sh)
+#endif
+#ifndef NVK_MERGE_WIDE_ROWS
+#define NVK_MERGE_WIDE_ROWS 4096 // (rows x q-heads) up to which the merge runs one workgroup per (row, head)
+#endif
 #ifndef NVK_AUTO_MAX_CHUNK
 #define NVK_AUTO_MAX_CHUNK 2048 // longest chunk NVK_DECODE_AUTO picks
 #endif
@@ -84,6 +90,7 @@ struct nvk_pool
     // split-K workspace (grown on demand, reused across calls)
     float *ws_o = nullptr, *ws_ml = nullptr;
     size_t ws_o_floats = 0, ws_ml_floats = 0;
+    long long ws_generation = 0; // bumped whenever the workspace moves (captured graphs hold its address)
 
     // the plan nvk_decode / nvk_decode_device rebuild on every call (callers that
     // reuse one plan across the layers of a model step own an nvk_plan instead)
@@ -158,6 +165,7 @@ int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
         }
         HIP_TRY(hipMalloc(&pool->ws_o, o_floats * sizeof(float)));
         pool->ws_o_floats = o_floats;
+        pool->ws_generation++;
     }
     if (ml_floats > pool->ws_ml_floats) {
         if (pool->ws_ml) {
@@ -168,6 +176,7 @@ int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
         }
         HIP_TRY(hipMalloc(&pool->ws_ml, ml_floats * sizeof(float)));
         pool->ws_ml_floats = ml_floats;
+        pool->ws_generation++;
     }
     return NVK_OK;
 }
@@ -265,12 +274,17 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
         // batch tolerates chunks up to 2048 tokens; 128 keeps the prologue/epilogue share small.
         const long long wg_per_chunk = std::max<long long>(1, (long long)plan->kv_groups * (kv_mul / plan->qpk));
         const long long tokens_upper = (long long)num_seqs * ctx_cap * wg_per_chunk;
-        chunk = round_up((int)std::min<long long>(1 << 20, (tokens_upper + pool->num_cus - 1) / pool->num_cus),
-                         NVK_AUTO_MIN_CHUNK);
-        chunk = std::max<long long>(NVK_AUTO_MIN_CHUNK, std::min<long long>(chunk, NVK_AUTO_MAX_CHUNK));
-        // at most 128 chunks per sequence: the merge walks a sequence's partials one after the other (one long
-        // sequence alone, 32K tokens: 171 us with 256 chunks of 128, 134 us with 128 chunks of 256)
-        chunk = std::max<long long>(chunk, round_up((ctx_cap + 127) / 128, NVK_AUTO_MIN_CHUNK));
+        // few (row, head) pairs: the merge takes its chunks side by side (nvk_merge_wide_kernel), so chunks may be
+        // shorter and more numerous -- the only way one request reaches more than a handful of CUs
+        const bool wide      = (long long)num_seqs * pool->n_kv_heads * kv_mul <= NVK_MERGE_WIDE_ROWS;
+        const int  min_chunk = wide ? NVK_AUTO_MIN_CHUNK_WIDE : NVK_AUTO_MIN_CHUNK;
+        const int  most      = wide ? nvk::kMergeWideMaxChunks : 128;
+        chunk = round_up((int)std::min<long long>(1 << 20, (tokens_upper + pool->num_cus - 1) / pool->num_cus), min_chunk);
+        chunk = std::max<long long>(min_chunk, std::min<long long>(chunk, NVK_AUTO_MAX_CHUNK));
+        // a bound on the chunks per sequence: nvk_merge_kernel walks a sequence's partials one after the other (one
+        // long sequence alone, 32K tokens: 171 us with 256 chunks of 128, 134 us with 128 chunks of 256), and
+        // nvk_merge_wide_kernel holds one chunk per thread
+        chunk = std::max<long long>(chunk, round_up((ctx_cap + most - 1) / most, min_chunk));
     }
     chunk = std::min<long long>(chunk, ctx_cap);
     chunk = std::min<long long>(chunk, slice_cap);
@@ -467,10 +481,20 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
         HIP_TRY(hipEventRecord(ev_attn_end, stream));
 
     if (sh.max_chunks > 1) {
-        const int  vecs = n_heads * (pool->head_dim / 4);
-        const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)((vecs + 255) / 256));
-        hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
-                           plan->counters + 1, out_dev, n_heads, pool->head_dim, sh.max_chunks);
+        // few rows cut into many chunks: one workgroup per (row, head), chunks side by side; otherwise a thread per
+        // output float4 walking its chunks (NVK_MERGE_WIDE_ROWS = 0 switches the first form off)
+        if (sh.max_chunks >= 4 && sh.max_chunks <= nvk::kMergeWideMaxChunks && n_heads <= 65535
+            && (long long)plan->num_seqs * n_heads <= NVK_MERGE_WIDE_ROWS) {
+            const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)n_heads);
+            hipLaunchKernelGGL(nvk::nvk_merge_wide_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
+                               plan->counters + 1, out_dev, n_heads, pool->head_dim, sh.max_chunks);
+        }
+        else {
+            const int  vecs = n_heads * (pool->head_dim / 4);
+            const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)((vecs + 255) / 256));
+            hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
+                               plan->counters + 1, out_dev, n_heads, pool->head_dim, sh.max_chunks);
+        }
         HIP_TRY(hipGetLastError());
     }
     return NVK_OK;
@@ -959,6 +983,8 @@ int nvk_pool_stream(const nvk_pool *pool, void **stream)
     *stream = (void *)pool->stream;
     return NVK_OK;
 }
+
+long long nvk_pool_workspace_generation(const nvk_pool *pool) { return pool ? pool->ws_generation : -1; }
 
 int nvk_pool_synchronize(nvk_pool *pool)
 {

@@ -55,6 +55,10 @@ class LlamaModel:
     def request_len(self, request_id: int) -> int:
         return _capi.check(_capi.lib.nvk_model_request_len(self._h, int(request_id)))
 
+    def use_graphs(self, on: bool) -> None:
+        """Replay pure decode steps as a hipGraph (default) or launch every kernel directly; same results."""
+        _capi.check(_capi.lib.nvk_model_use_graphs(self._h, int(bool(on))))
+
     @property
     def free_blocks(self) -> int:
         return int(_capi.lib.nvk_model_free_blocks(self._h))
