@@ -185,3 +185,31 @@ def test_device_model_batched_requests_equal_their_single_runs(checkpoints):
             step += 1
         assert streams == alone
         assert m.free_blocks == spec["num_blocks"]
+
+
+@pytest.mark.parametrize("n_requests", [1, 3])
+@pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])
+def test_graph_replay_gives_the_bits_of_direct_launches(spec, n_requests, checkpoints):
+    """Pure decode steps replay a hipGraph (recorded the second time a launch shape is seen, recorded again when the
+    plan's shape changes as the contexts grow): every step's logits must equal, bit for bit, those of launching the
+    same kernels one by one."""
+    import nano_vllm_amd as nv
+
+    rng = np.random.default_rng(11)
+    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=k).tolist() for k in (5, 9, 2)][:n_requests]
+    ids = list(range(10, 10 + n_requests))
+    steps = min(40, spec["max_seq_len"] - 12)
+    runs = {}
+    for graphs in (False, True):
+        with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"], max_seqs=3) as m:
+            m.use_graphs(graphs)
+            for r in ids:
+                m.add_request(r)
+            nxt, logits = m.step_chunks(ids, prompts, True)
+            got = [logits.copy()]
+            for _ in range(steps):
+                nxt, logits = m.step(ids, nxt.tolist(), True)
+                got.append(logits.copy())
+            runs[graphs] = np.stack(got)
+    assert np.isfinite(runs[False]).all()
+    assert np.array_equal(runs[True], runs[False])
