@@ -46,13 +46,12 @@
 #define NVK_GEMV_COLS 4 // weight rows (output columns) per GEMV workgroup: 4, 8 or 16.  Measured per shape
                         // (tools/gemv_sweep.sh, profiles/r01_qkv_projection.log): 4 is the fastest for one row at every
                         // size (2048 x 2048 is 512 workgroups instead of 128, and fewer registers let more of them
-                        // share a CU), and for two rows up to a few thousand columns
+                        // share a CU), and for two rows up to a few thousand columns (NVK_GEMV2_MAX_COLS)
 #endif
-#ifndef NVK_GEMV2_WIDE_COLS
-#define NVK_GEMV2_WIDE_COLS 16 // two rows and more than NVK_GEMV2_WIDE_FROM columns: 16 per workgroup
-#endif
-#ifndef NVK_GEMV2_WIDE_FROM
-#define NVK_GEMV2_WIDE_FROM 4096
+#ifndef NVK_GEMV2_MAX_COLS
+#define NVK_GEMV2_MAX_COLS 4096 // two rows: the GEMV up to this many output columns, above it the 16 x 16 MFMA kernel
+                                // (measured: 2 x 5632 columns 22.6 us GEMV / 18.9 us MFMA, 32000 columns 50.2 / 44.8;
+                                // 2560 columns 6.4 / 7.6, 2048 columns of 5632 floats 10.3 / 15.9)
 #endif
 #ifndef NVK_GEMV_DEPTH
 #define NVK_GEMV_DEPTH 2 // steps of weight loads a GEMV wave keeps in flight
@@ -521,7 +520,7 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
 // ---- C = A . W^T, at most 8 rows: the reference's own case (one token: Ops::matmul is a GEMV) -------
 // HBM-bound: every weight byte is read once and multiplied on the vector ALUs (an MFMA tile padded to 32
 // rows would cost as much time as the stream itself).  One workgroup = kGemvCols output columns (weight rows:
-// 4, or 16 for two rows of a wide output), 8 waves dealing the contraction round-robin in steps of 64; a lane holds
+// 4), 8 waves dealing the contraction round-robin in steps of 64; a lane holds
 // a float4 of kGemvCols / 4 weight rows per step (256 contiguous bytes per row and instruction), two steps in flight, and the matching float4
 // of every activation row (L2-resident).  Per lane partial sums -> DPP row sum over the 16 lanes of a
 // weight row -> the eight waves meet in LDS.  An output's summation order depends on k only.
@@ -648,7 +647,10 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: a %d x %d weight exceeds 2^31 floats", who, n[s], in_dim);
     nvk::LinearParams p;
     p.a = in, p.m = batch, p.k = in_dim, p.lda = in_dim;
-    const bool gemv   = batch <= NVK_GEMV_MAX_ROWS;
+    long long cols = 0;
+    for (int s = 0; s < nseg; s++)
+        cols += n[s];
+    const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS);
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
     int bm = 128, bn = 128;
@@ -671,13 +673,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         if (NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
             bm = bn = 64;
     }
-    else {
-        long long cols = 0;
-        for (int s = 0; s < nseg; s++)
-            cols += n[s];
-        const int gemv_cols = batch == 2 && cols > NVK_GEMV2_WIDE_FROM ? NVK_GEMV2_WIDE_COLS : NVK_GEMV_COLS;
-        bn = gemv ? (batch <= 2 ? gemv_cols : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
-    }
+    else
+        bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
     long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
@@ -697,10 +694,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         const dim3 grid((unsigned)tiles), block(64 * nvk::kGemvWaves);
         if (batch == 1)
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
-        else if (batch == 2 && bn == NVK_GEMV_COLS)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
         else if (batch == 2)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV2_WIDE_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
 #if NVK_GEMV_MAX_ROWS > 2
         else
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<4, 32, 2>), grid, block, 0, st, p);
