@@ -154,6 +154,13 @@ int nvk_batch_add_rms_norm_device(float *out_dev, float *x_dev, const float *add
                                   int batch_size, int dim, float eps, int device, void *stream);
 int nvk_batch_matmul_device(float *out_dev, const float *in_dev, const float *weight_dev, int batch_size, int in_dim,
                             int out_dim, int device, void *stream);
+/* The gated half of the feed-forward block, model.hpp:232-234: hb = silu(w_gate . in) * (w_up . in), silu(g) =
+ * g / (1 + expf(-g)) (Ops::swiglu, include/ops/activation.hpp:34-40).  hb_dev [batch_size, hidden_dim] receives the
+ * result; hb2_dev (same shape, distinct) is scratch whose contents are unspecified afterwards.  With one or two rows
+ * SwiGLU runs in the epilogue of the GEMV (one launch; the bits of the two products followed by SwiGLU); with more
+ * rows it is nvk_batch_matmul2_device followed by the element-wise kernel. */
+int nvk_batch_swiglu_ffn_device(float *hb_dev, float *hb2_dev, const float *in_dev, const float *w_gate_dev,
+                                const float *w_up_dev, int batch_size, int in_dim, int hidden_dim, int device, void *stream);
 /* two products over the same activations in one launch (w_gate and w_up, include/core/model.hpp:232-233) */
 int nvk_batch_matmul2_device(float *out_a_dev, float *out_b_dev, const float *in_dev, const float *weight_a_dev,
                              const float *weight_b_dev, int batch_size, int in_dim, int out_dim_a, int out_dim_b,

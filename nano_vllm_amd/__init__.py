@@ -14,10 +14,10 @@ from .block_manager import BlockManager
 from .kv_pool import PagedKVPool
 from .model import LlamaModel
 from .tokenizer import Tokenizer
-from .linear import batch_add_rms_norm_device, batch_matmul2_device, batch_matmul_device, batch_rms_norm_device, qkv_project_device
+from .linear import batch_add_rms_norm_device, batch_matmul2_device, batch_swiglu_ffn_device, batch_matmul_device, batch_rms_norm_device, qkv_project_device
 from .prefill import PREFILL_AUTO, PREFILL_ROWWISE, PREFILL_TILED, prefill, prefill_device, rope_append_chunks
 
 __all__ = [
-    "AUTO", "PREFILL_AUTO", "PREFILL_ROWWISE", "PREFILL_TILED", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "LlamaModel", "NvkError", "PagedKVPool", "Tokenizer", "batch_add_rms_norm_device", "batch_matmul2_device", "batch_matmul_device", "batch_rms_norm_device", "bind_pool", "decode",
+    "AUTO", "PREFILL_AUTO", "PREFILL_ROWWISE", "PREFILL_TILED", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "LlamaModel", "NvkError", "PagedKVPool", "Tokenizer", "batch_add_rms_norm_device", "batch_matmul2_device", "batch_matmul_device", "batch_swiglu_ffn_device", "batch_rms_norm_device", "bind_pool", "decode",
     "decode_bench", "decode_device", "device_count", "host_cache_staged_bytes", "paged_attention", "prefill", "prefill_device", "qkv_project_device", "rope_append_chunks", "set_host_cache_policy", "standard_attention", "version",
 ]

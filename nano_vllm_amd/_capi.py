@@ -79,6 +79,7 @@ SIGNATURES = {
     "nvk_batch_add_rms_norm_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp]),
     "nvk_batch_matmul_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "nvk_batch_matmul2_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "nvk_batch_swiglu_ffn_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "nvk_qkv_project_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_float, C.c_int, _vp]),
     "nvk_prefill_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),

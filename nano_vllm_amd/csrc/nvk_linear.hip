@@ -517,30 +517,38 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     }
 }
 
-// ---- C = A . W^T, at most 8 rows: the reference's own case (one token: Ops::matmul is a GEMV) -------
+// ---- C = A . W^T, one or two rows: the reference's own case (one token: Ops::matmul is a GEMV) -------
 // HBM-bound: every weight byte is read once and multiplied on the vector ALUs (an MFMA tile padded to 32
-// rows would cost as much time as the stream itself).  One workgroup = kGemvCols output columns (weight rows:
-// 4), 8 waves dealing the contraction round-robin in steps of 64; a lane holds
-// a float4 of kGemvCols / 4 weight rows per step (256 contiguous bytes per row and instruction), two steps in flight, and the matching float4
-// of every activation row (L2-resident).  Per lane partial sums -> DPP row sum over the 16 lanes of a
-// weight row -> the eight waves meet in LDS.  An output's summation order depends on k only.
+// rows would cost as much time as the stream itself).  One workgroup = kGemvCols output columns (weight rows: 4),
+// 8 waves dealing the contraction round-robin in steps of 64; a lane holds a float4 of kGemvCols / 4 weight rows
+// per step (256 contiguous bytes per row and instruction), two steps in flight, and the matching float4 of every
+// activation row (L2-resident).  Per lane partial sums -> DPP row sum over the 16 lanes of a weight row -> the eight
+// waves meet in LDS.  An output's summation order depends on k only.
+// GLU (kGemvCols = 4, two segments of equal n: w_gate, w_up): the workgroup's four weight rows are gate rows n0, n0 + 1
+// and the same two rows of up, and it writes silu(gate) * up to the first segment's output (Ops::swiglu,
+// activation.hpp:34-40) -- one launch less per layer where a launch costs as much as the work.  Each 16-lane group
+// walks k in the order the plain kernel uses for its column, so the sums (and, expf being the same function, the
+// products) have the bits of nvk_batch_matmul2_device followed by the separate SwiGLU kernel.
 constexpr int kGemvWaves = 8, kGemvBK = 64;
 
-template <int M, int kGemvCols, int DEPTH>
+template <int M, int kGemvCols, int DEPTH, bool GLU = false>
 __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
 {
+    static_assert(!GLU || kGemvCols == 4, "GLU pairs two gate rows with two up rows");
     __shared__ float s_red[kGemvWaves][M][kGemvCols];
-    const int       nt = blockIdx.x;
-    const LinearSeg sg = segment_of(p, nt);
-    const int       n0 = (nt - sg.tile0) * kGemvCols;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane >> 4, lc = (lane & 15) * 4;
+    // GLU: lane groups 0, 1 carry gate rows n0, n0 + 1, groups 2, 3 the same rows of up; `nt` is the tile the plain
+    // kernel would give the group's column (it sets where the walk over k starts)
+    const LinearSeg sg = GLU ? p.seg[lr >> 1] : segment_of(p, blockIdx.x);
+    const int       n0 = GLU ? (int)blockIdx.x * 2 : ((int)blockIdx.x - sg.tile0) * kGemvCols;
+    const int       nt = GLU ? sg.tile0 + n0 / kGemvCols : (int)blockIdx.x;
 
     constexpr int R = kGemvCols / 4; // weight rows per lane
     int woff[R], xoff[M];
 #pragma unroll
     for (int i = 0; i < R; i++)
-        woff[i] = min(n0 + lr + 4 * i, sg.n - 1) * p.k + lc;
+        woff[i] = min(n0 + (GLU ? lr & 1 : lr + 4 * i), sg.n - 1) * p.k + lc;
 #pragma unroll
     for (int m = 0; m < M; m++)
         xoff[m] = min(m, p.m - 1) * p.lda + lc;
@@ -605,7 +613,21 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
                 s_red[wave][m][lr + 4 * i] = v;
         }
     __syncthreads();
-    if (tid < M * kGemvCols) {
+    if (GLU) {
+        if (tid < M * 2) {
+            const int m = tid / 2, c = tid % 2;
+            float     gate = 0.f, up = 0.f;
+#pragma unroll
+            for (int w = 0; w < kGemvWaves; w++)
+                gate += s_red[w][m][c], up += s_red[w][m][c + 2];
+            if (m < p.m && n0 + c < p.seg[0].n) {
+#pragma clang fp contract(off) // val = g / (1 + expf(-g)); val * up -- two roundings, as the separate kernel
+                const float val = gate / (1.0f + expf(-gate));
+                p.seg[0].out[(int64_t)m * p.seg[0].ldo + n0 + c] = val * up;
+            }
+        }
+    }
+    else if (tid < M * kGemvCols) {
         const int m = tid / kGemvCols, c = tid % kGemvCols;
         float     sum = 0.f;
 #pragma unroll
@@ -613,6 +635,17 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
             sum += s_red[w][m][c];
         if (m < p.m && n0 + c < sg.n)
             sg.out[(int64_t)m * sg.ldo + n0 + c] = sum;
+    }
+}
+
+// hb = silu(hb) * up, silu(g) = g / (1 + expf(-g))  (Ops::swiglu, include/ops/activation.hpp:34-40)
+__global__ void nvk_swiglu_kernel(float *__restrict__ hb, const float *__restrict__ up, int64_t n)
+{
+#pragma clang fp contract(off)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g   = hb[i];
+        const float val = g / (1.0f + expf(-g));
+        hb[i]           = val * up[i];
     }
 }
 
@@ -634,7 +667,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // One launch for up to three (weight, out, n) segments sharing the activations `in` [batch, in_dim].
 int launch_linear(const float *in, int batch, int in_dim, const float *const *w, float *const *out, const int *n,
-                  int nseg, int device, hipStream_t st, const char *who)
+                  int nseg, int device, hipStream_t st, const char *who, bool glu = false)
 {
     if (in_dim % 4 != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: in_dim=%d must be a multiple of 4", who, in_dim);
@@ -652,6 +685,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         cols += n[s];
     const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS);
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
+    if (glu && !(gemv && NVK_GEMV_COLS == 4 && nseg == 2 && n[0] == n[1] && n[0] > 0))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the GLU form needs the GEMV and two equal segments", who);
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
     int bm = 128, bn = 128;
     if (!gemv && !skinny) {
@@ -691,8 +726,12 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     p.n_tiles = (int)tiles;
     if (gemv) {
         p.m_tiles = 1;
-        const dim3 grid((unsigned)tiles), block(64 * nvk::kGemvWaves);
-        if (batch == 1)
+        const dim3 grid((unsigned)(glu ? (n[0] + 1) / 2 : tiles)), block(64 * nvk::kGemvWaves);
+        if (glu && batch == 1)
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, 4, NVK_GEMV_DEPTH, true>), grid, block, 0, st, p);
+        else if (glu)
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, 4, NVK_GEMV_DEPTH, true>), grid, block, 0, st, p);
+        else if (batch == 1)
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
         else if (batch == 2)
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
@@ -832,6 +871,33 @@ int nvk_batch_matmul2_device(float *out_a_dev, float *out_b_dev, const float *in
     float *const       out[2] = {out_a_dev, out_b_dev};
     const int          n[2]   = {out_dim_a, out_dim_b};
     return launch_linear(in_dev, batch_size, in_dim, w, out, n, 2, device, (hipStream_t)stream, "nvk_batch_matmul2_device");
+}
+
+int nvk_batch_swiglu_ffn_device(float *hb_dev, float *hb2_dev, const float *in_dev, const float *w_gate_dev,
+                                const float *w_up_dev, int batch_size, int in_dim, int hidden_dim, int device, void *stream)
+{
+    if (batch_size < 0 || in_dim <= 0 || hidden_dim <= 0
+        || (batch_size > 0 && (!hb_dev || !hb2_dev || !in_dev || !w_gate_dev || !w_up_dev)) || hb_dev == hb2_dev)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_swiglu_ffn_device: bad arguments");
+    int rc = check_device(device, "nvk_batch_swiglu_ffn_device");
+    if (rc != NVK_OK || batch_size == 0)
+        return rc;
+    nvk::DeviceScope   scope(device);
+    const float *const w[2]   = {w_gate_dev, w_up_dev};
+    float *const       out[2] = {hb_dev, hb2_dev};
+    const int          n[2]   = {hidden_dim, hidden_dim};
+    // one or two rows on the GEMV: SwiGLU in its epilogue (hb2 is not touched); otherwise the two products, then SwiGLU
+    const bool gemv = NVK_GEMV_COLS == 4 && batch_size <= NVK_GEMV_MAX_ROWS
+                      && (batch_size < 2 || 2LL * hidden_dim <= NVK_GEMV2_MAX_COLS);
+    rc = launch_linear(in_dev, batch_size, in_dim, w, out, n, 2, device, (hipStream_t)stream, "nvk_batch_swiglu_ffn_device",
+                       gemv);
+    if (rc != NVK_OK || gemv)
+        return rc;
+    const int64_t count = (int64_t)batch_size * hidden_dim;
+    hipLaunchKernelGGL(nvk::nvk_swiglu_kernel, dim3((unsigned)std::min<int64_t>(1024, (count + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, hb_dev, hb2_dev, count);
+    HIP_TRY(hipGetLastError());
+    return NVK_OK;
 }
 
 int nvk_qkv_project_device(float *q_dev, float *k_dev, float *v_dev, const float *x_dev, float *xb_dev,

@@ -59,17 +59,6 @@ __global__ void nvk_residual_kernel(float *__restrict__ x, const float *__restri
     }
 }
 
-// hb = silu(gate) * up, silu(g) = g / (1 + expf(-g))  (Ops::swiglu, include/ops/activation.hpp:34-40)
-__global__ void nvk_swiglu_kernel(float *__restrict__ hb, const float *__restrict__ up, int64_t n)
-{
-#pragma clang fp contract(off)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float g   = hb[i];
-        const float val = g / (1.0f + expf(-g));
-        hb[i]           = val * up[i];
-    }
-}
-
 // dst[i] = src[rows[i]]: each request's last row (the only one whose logits are wanted)
 __global__ void nvk_take_rows_kernel(float *__restrict__ dst, const float *__restrict__ src, const int *__restrict__ rows,
                                      int dim)
@@ -489,11 +478,10 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
                 r2 = nvk_batch_matmul_device(m->xb, m->att, w.wo, R, QD, D, m->device, (void *)st); // :224
             if (r2 == NVK_OK) // :227-231: x += xb; xn = rms_norm(x, rms_ffn)
                 r2 = nvk_batch_add_rms_norm_device(m->xn, m->x, m->xb, w.rms_ffn, R, D, m->rms_eps, m->device, (void *)st);
-            if (r2 == NVK_OK) // :232-233
-                r2 = nvk_batch_matmul2_device(m->hb, m->hb2, m->xn, w.w_gate, w.w_up, R, D, Hd, Hd, m->device, (void *)st);
+            if (r2 == NVK_OK) // :232-234: hb = silu(w_gate . xn) * (w_up . xn)
+                r2 = nvk_batch_swiglu_ffn_device(m->hb, m->hb2, m->xn, w.w_gate, w.w_up, R, D, Hd, m->device, (void *)st);
             if (r2 != NVK_OK)
                 break;
-            hipLaunchKernelGGL(nvk_swiglu_kernel, dim3(ew_blocks), dim3(256), 0, st, m->hb, m->hb2, (int64_t)R * Hd); // :234
             r2 = nvk_batch_matmul_device(m->xb, m->hb, w.w_down, R, Hd, D, m->device, (void *)st);                    // :235
             if (r2 != NVK_OK)
                 break;
@@ -502,14 +490,18 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
                                                    m->device, (void *)st);
                 attn_in = m->xn;
             }
+            else if (R == n) // every row is a request's last row: the last add rides in the final norm (:238-239, :243)
+                r2 = nvk_batch_add_rms_norm_device(m->xl, m->x, m->xb, m->rms_final, n, D, m->rms_eps, m->device, (void *)st);
             else
                 hipLaunchKernelGGL(nvk_residual_kernel, dim3(ew_blocks), dim3(256), 0, st, m->x, m->xb, (int64_t)R * D / 4);
         }
         if (r2 != NVK_OK)
             return r2;
         // final norm + classifier for each request's last row only (model.hpp:243-246), then the greedy sampler
-        hipLaunchKernelGGL(nvk_take_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, m->xl, m->x, m->last_rows_dev, D);
-        r2 = nvk_batch_rms_norm_device(m->xl, m->xl, m->rms_final, n, D, m->rms_eps, m->device, (void *)st);
+        if (R != n) {
+            hipLaunchKernelGGL(nvk_take_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, m->xl, m->x, m->last_rows_dev, D);
+            r2 = nvk_batch_rms_norm_device(m->xl, m->xl, m->rms_final, n, D, m->rms_eps, m->device, (void *)st);
+        }
         if (r2 == NVK_OK)
             r2 = nvk_batch_matmul_device(m->logits, m->xl, m->lm_head, n, D, V, m->device, (void *)st);
         if (r2 != NVK_OK)

@@ -44,6 +44,14 @@ def batch_matmul2_device(out_a_dev, out_b_dev, in_dev, weight_a_dev, weight_b_de
                                                    _devptr(stream)))
 
 
+def batch_swiglu_ffn_device(hb_dev, hb2_dev, in_dev, w_gate_dev, w_up_dev, batch_size: int, in_dim: int, hidden_dim: int,
+                            device: int = 0, stream=None) -> None:
+    """hb = silu(w_gate . in) * (w_up . in) (model.hpp:232-234, Ops::swiglu); hb2 is scratch."""
+    _capi.check(_capi.lib.nvk_batch_swiglu_ffn_device(_devptr(hb_dev), _devptr(hb2_dev), _devptr(in_dev),
+                                                      _devptr(w_gate_dev), _devptr(w_up_dev), int(batch_size),
+                                                      int(in_dim), int(hidden_dim), int(device), _devptr(stream)))
+
+
 def qkv_project_device(q_dev, k_dev, v_dev, x_dev, xb_dev, rms_weight_dev, wq_dev, wk_dev, wv_dev, batch_size: int,
                        dim: int, q_dim: int, kv_dim: int, rms_eps: float = RMS_EPS, device: int = 0, stream=None) -> None:
     """xb = rms_norm(x, rms_weight); q, k, v = wq.xb, wk.xb, wv.xb in one launch (model.hpp:161-166)."""

@@ -189,6 +189,33 @@ def test_two_products_in_one_launch(B, nv, DA):
     assert close(ob.numpy(), sb.numpy())  # the second segment's tiles start elsewhere in k than in a launch of its own
 
 
+@pytest.mark.parametrize("B", [1, 2, 5])
+@pytest.mark.parametrize("H", [200, 201, 2100])
+def test_gated_ffn_half_with_swiglu_in_the_epilogue(B, H, nv, DA):
+    """nvk_batch_swiglu_ffn_device (model.hpp:232-234): with one or two rows SwiGLU runs in the GEMV's epilogue (two
+    gate rows and two up rows per workgroup, each walking k as the plain kernel does for its column), otherwise
+    after the two products.  Either way the result is silu(gate) * up of nvk_batch_matmul2_device's own outputs --
+    compared here to 2 ulp (numpy's float32 exp against the device's expf) -- and the checker's within the bar."""
+    D = 96
+    x = uniform(1200 + B, 0, B * D).reshape(B, D)
+    wg = (uniform(1201, 0, H * D) * np.float32(0.2)).reshape(H, D)
+    wu = (uniform(1202, 0, H * D) * np.float32(0.2)).reshape(H, D)
+    dx, dwg, dwu = DA(x), DA(wg), DA(wu)
+    hb, hb2 = DA(np.full((B, H), np.nan, np.float32)), DA(np.full((B, H), np.nan, np.float32))
+    nv.batch_swiglu_ffn_device(hb, hb2, dx, dwg, dwu, B, D, H)
+    g, u = DA(np.zeros((B, H), np.float32)), DA(np.zeros((B, H), np.float32))
+    nv.batch_matmul2_device(g, u, dx, dwg, dwu, B, D, H, H)
+    gate, up = g.numpy(), u.numpy()
+    want = (gate / (np.float32(1) + np.exp(-gate, dtype=np.float32))) * up
+    got = hb.numpy()
+    assert np.all(np.abs(got - want) <= 3e-7 * np.abs(want) + 1e-30), float(np.abs(got - want).max())
+    og = ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x, wg)
+    ou = ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x, wu)
+    assert close(got, (og / (np.float32(1) + np.exp(-og, dtype=np.float32))) * ou)
+    with pytest.raises(nv.NvkError):
+        nv.batch_swiglu_ffn_device(hb, hb, dx, dwg, dwu, B, D, H)  # the scratch must be a buffer of its own
+
+
 def test_argument_errors(nv, DA):
     a = DA(np.zeros((4, 8), np.float32))
     with pytest.raises(nv.NvkError):
