@@ -598,6 +598,26 @@ int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim,
         HIP_TRY(hipMalloc((void **)&b->h_xb, r * d * sizeof(float)));
         b->h_rows = r, b->h_dim = d, b->h_qdim = qdim;
     }
+    // One or two decoding rows: the projections, the rotation and the append are one launch (the GEMV's epilogue
+    // writes where nvk_rope_append_kernel would: same arithmetic, same bits, one kernel and two scratch rows less).
+    const bool all_decode = !b->chunked || b->n_decode == (int)b->step_ids.size();
+    if (all_decode && rope_theta > 0.f && b->head_dim % 2 == 0
+        && nvk::qkv_rope_append_ok(rows, dim, (int)qdim, b->row_len)) {
+        const float *act = x_dev;
+        if (rms_weight_dev) { // model.hpp:161
+            int rc = nvk_batch_rms_norm_device(b->h_xb, x_dev, rms_weight_dev, rows, dim, rms_eps, b->device, (void *)st);
+            if (rc != NVK_OK)
+                return rc;
+            act = b->h_xb;
+        }
+        nvk::RopeAppendTarget target;
+        int rc = nvk::pool_rope_append_target(b->pool, layer, rope_theta, b->d_tables, b->max_blocks, b->d_pos, &target);
+        if (rc == NVK_OK) // model.hpp:164-175, 190-207
+            rc = nvk::qkv_rope_append(target, b->h_q, act, wq_dev, wk_dev, wv_dev, rows, dim, (int)qdim, b->device, (void *)st);
+        if (rc != NVK_OK)
+            return rc;
+        return nvk_decode_planned(b->pool, layer, b->plan, b->h_q, b->d_tables, b->max_blocks, out_dev, (void *)st); // :221
+    }
     // model.hpp:161-166: xb = rms_norm(x), q / k / v = wq / wk / wv . xb -- then :169-221 as nvk_batch_layer
     int rc = nvk_qkv_project_device(b->h_q, b->h_k, b->h_v, x_dev, b->h_xb, rms_weight_dev, wq_dev, wk_dev, wv_dev, rows,
                                     dim, (int)qdim, b->row_len, rms_eps, b->device, (void *)st);

@@ -49,6 +49,8 @@
 #define NVK_NT_LOADS 1 // 1: K/V loads carry the non-temporal hint (read-once stream)
 #endif
 
+#include "nvk_addr.hip.h" // token_block, token_offset, row_float_index, clamp_block, rope_rotate
+
 namespace nvk {
 
 // A pipeline step is kStepTokens tokens per wave: 4 token slots x kTokPerLane tokens each.
@@ -106,27 +108,6 @@ struct DecodeParams
     int             items_padded; // item slots per (kv-head group, q sub-group): the item bound, a multiple of 8 when qsplit > 1
     float           q_scale;   // log2(e) / sqrt(head_dim)
 };
-
-// ---- address arithmetic shared by decode, gather and append ---------------
-// t / block_size without a divide and without a branch: bs_magic = ceil(2^32 / block_size),
-// exact for t < 2^32 / block_size (checked on the host); block_size 1 has magic 0 (2^32 does not fit).
-__device__ __forceinline__ int token_block(int tok, unsigned bs_magic)
-{
-    const unsigned whole = bs_magic ? 0u : 0xFFFFFFFFu; // uniform; keeps the lane code branch-free
-    return (int)(__umulhi((unsigned)tok, bs_magic) + ((unsigned)tok & whole));
-}
-__device__ __forceinline__ int token_offset(int tok, int blk, int block_size) { return tok - blk * block_size; }
-// float index of element 0 of (physical block, offset, kv head) inside a layer slab
-__device__ __forceinline__ int64_t row_float_index(int physical_block, int block_offset, int kv_head,
-                                                   int block_size, int n_kv_heads, int head_dim)
-{
-    return (((int64_t)physical_block * block_size + block_offset) * n_kv_heads + kv_head) * (int64_t)head_dim;
-}
-// A table entry the reference would treat as undefined behaviour must not fault the GPU.
-__device__ __forceinline__ int clamp_block(int id, int num_blocks)
-{
-    return (int)min((unsigned)id, (unsigned)(num_blocks - 1));
-}
 
 // ---- wave-level helpers ---------------------------------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_move(float x)
@@ -1050,13 +1031,6 @@ __global__ void __launch_bounds__(256, NVK_PREFILL_MIN_WAVES) nvk_prefill_kernel
 // straight to the pool slot of token `pos` (k_rows itself is left untouched).
 // (hipcc contracts a*b - c*d into an fma by default, and __fmul_rn/__fsub_rn are plain operators
 // in this ROCm: the pragma is what keeps the four products and the two sums separately rounded)
-__device__ __forceinline__ float2 rope_rotate(float2 v, float2 cs)
-{
-#pragma clang fp contract(off)
-    const float xc = v.x * cs.x, ys = v.y * cs.y, xs = v.x * cs.y, yc = v.y * cs.x;
-    return make_float2(xc - ys, xs + yc);
-}
-
 __global__ void __launch_bounds__(256)
     nvk_rope_append_kernel(float *__restrict__ k_layer, float *__restrict__ v_layer, float *__restrict__ q,
                            const float *__restrict__ k_rows, const float *__restrict__ v_rows,

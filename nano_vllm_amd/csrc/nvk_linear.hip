@@ -26,6 +26,7 @@
 #include <algorithm>
 
 #include "nvk_device_scope.h"
+#include "nvk_addr.hip.h"
 #include "nvk_internal.h"
 
 #define HIP_TRY(expr)                                                                                                  \
@@ -96,6 +97,7 @@ struct LinearParams
     int          m, k, lda;
     LinearSeg    seg[3];
     int          nseg, n_tiles, m_tiles;
+    RopeAppendTarget rope; // nvk_gemv_kernel<.., ROPE>: where the q / k / v epilogue writes
 };
 
 __device__ __forceinline__ const LinearSeg &segment_of(const LinearParams &p, int tile)
@@ -531,10 +533,14 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
 // products) have the bits of nvk_batch_matmul2_device followed by the separate SwiGLU kernel.
 constexpr int kGemvWaves = 8, kGemvBK = 64;
 
-template <int M, int kGemvCols, int DEPTH, bool GLU = false>
+// ROPE (kGemvCols = 4, the three segments wq, wk, wv): the epilogue is nvk_rope_append_kernel -- q and k columns are
+// rotated in their pairs (both columns of a pair are in the workgroup's tile) by the row's position, q goes to the
+// first segment's output, k and v straight to the row's slot in the paged cache.  Same expressions, same bits.
+template <int M, int kGemvCols, int DEPTH, bool GLU = false, bool ROPE = false>
 __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
 {
     static_assert(!GLU || kGemvCols == 4, "GLU pairs two gate rows with two up rows");
+    static_assert(!ROPE || (kGemvCols == 4 && !GLU), "ROPE needs a rotation pair inside the tile");
     __shared__ float s_red[kGemvWaves][M][kGemvCols];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane >> 4, lc = (lane & 15) * 4;
@@ -627,6 +633,38 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
             }
         }
     }
+    else if (ROPE) {
+        if (tid < M * kGemvCols) {
+            const int m = tid / kGemvCols, c = tid % kGemvCols, n = n0 + c;
+            float     sum = 0.f, mate = 0.f; // this column and the other one of its pair
+#pragma unroll
+            for (int w = 0; w < kGemvWaves; w++)
+                sum += s_red[w][m][c], mate += s_red[w][m][c ^ 1];
+            const RopeAppendTarget &t  = p.rope;
+            const int               si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
+            const int               pos = m < p.m ? t.positions[m] : -1;
+            if (pos >= 0 && n < sg.n) { // (a negative position: the row is skipped, as nvk_rope_append_kernel does)
+                float val = sum;
+                if (si < 2) { // q, k: positional.hpp:13-39 as nvk_rope_append_kernel evaluates it
+                    const float angle = (float)pos * t.inv_freq[(n % t.head_dim) >> 1];
+                    double      sn, cn;
+                    sincos((double)angle, &sn, &cn);
+                    const float2 r = rope_rotate(c & 1 ? make_float2(mate, sum) : make_float2(sum, mate),
+                                                 make_float2((float)cn, (float)sn));
+                    val            = c & 1 ? r.y : r.x;
+                }
+                if (si == 0)
+                    sg.out[(int64_t)m * sg.ldo + n] = val;
+                else { // model.hpp:190-207: the slot of token `pos` in the row's sequence
+                    const int     blk = token_block(pos, t.bs_magic);
+                    const int     off = token_offset(pos, blk, t.block_size);
+                    const int     pb  = clamp_block(t.block_tables[(int64_t)m * t.max_blocks + blk], t.num_blocks);
+                    const int64_t at  = ((int64_t)pb * t.block_size + off) * t.row_len + n;
+                    (si == 1 ? t.k_layer : t.v_layer)[at] = val;
+                }
+            }
+        }
+    }
     else if (tid < M * kGemvCols) {
         const int m = tid / kGemvCols, c = tid % kGemvCols;
         float     sum = 0.f;
@@ -667,7 +705,8 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // One launch for up to three (weight, out, n) segments sharing the activations `in` [batch, in_dim].
 int launch_linear(const float *in, int batch, int in_dim, const float *const *w, float *const *out, const int *n,
-                  int nseg, int device, hipStream_t st, const char *who, bool glu = false)
+                  int nseg, int device, hipStream_t st, const char *who, bool glu = false,
+                  const nvk::RopeAppendTarget *rope = nullptr)
 {
     if (in_dim % 4 != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: in_dim=%d must be a multiple of 4", who, in_dim);
@@ -685,6 +724,10 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         cols += n[s];
     const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS);
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
+    if (rope && !(gemv && NVK_GEMV_COLS == 4 && nseg == 3 && !glu))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the RoPE epilogue needs the GEMV and q, k, v segments", who);
+    if (rope)
+        p.rope = *rope;
     if (glu && !(gemv && NVK_GEMV_COLS == 4 && nseg == 2 && n[0] == n[1] && n[0] > 0))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the GLU form needs the GEMV and two equal segments", who);
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
@@ -731,6 +774,10 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, 4, NVK_GEMV_DEPTH, true>), grid, block, 0, st, p);
         else if (glu)
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, 4, NVK_GEMV_DEPTH, true>), grid, block, 0, st, p);
+        else if (rope && batch == 1)
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, 4, NVK_GEMV_DEPTH, false, true>), grid, block, 0, st, p);
+        else if (rope)
+            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, 4, NVK_GEMV_DEPTH, false, true>), grid, block, 0, st, p);
         else if (batch == 1)
             hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
         else if (batch == 2)
@@ -805,6 +852,33 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
 }
 
 } // namespace
+
+int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x_dev, const float *wq_dev,
+                         const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream)
+{
+    if (rows < 1 || rows > kQkvRopeMaxRows || rows > NVK_GEMV_MAX_ROWS || NVK_GEMV_COLS != 4 || dim <= 0 || q_dim <= 0
+        || !q_dev || !x_dev || !wq_dev || !wk_dev || !wv_dev || t.head_dim <= 0 || t.head_dim % 2 != 0
+        || q_dim % t.head_dim != 0 || t.row_len % t.head_dim != 0 || !t.k_layer || !t.v_layer || !t.block_tables
+        || !t.positions || !t.inv_freq)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "qkv_rope_append: bad arguments");
+    if (rows == 2 && (long long)q_dim + 2LL * t.row_len > NVK_GEMV2_MAX_COLS)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "qkv_rope_append: two rows of %d columns are not a GEMV", q_dim + 2 * t.row_len);
+    int rc = check_device(device, "qkv_rope_append");
+    if (rc != NVK_OK)
+        return rc;
+    nvk::DeviceScope   scope(device);
+    const float *const w[3]   = {wq_dev, wk_dev, wv_dev};
+    float *const       out[3] = {q_dev, q_dev, q_dev}; // k and v go to the cache
+    const int          n[3]   = {q_dim, t.row_len, t.row_len};
+    return launch_linear(x_dev, rows, dim, w, out, n, 3, device, (hipStream_t)stream, "qkv_rope_append", false, &t);
+}
+
+// can rows x (q_dim + 2 kv_dim) go through qkv_rope_append?
+bool nvk::qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim)
+{
+    return NVK_GEMV_COLS == 4 && rows >= 1 && rows <= kQkvRopeMaxRows && rows <= NVK_GEMV_MAX_ROWS && dim % 4 == 0
+           && (rows < 2 || (long long)q_dim + 2LL * kv_dim <= NVK_GEMV2_MAX_COLS);
+}
 
 extern "C" {
 

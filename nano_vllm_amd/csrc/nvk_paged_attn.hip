@@ -1154,6 +1154,29 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
     return NVK_OK;
 }
 
+} // extern "C"
+
+int nvk::pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const int *block_tables_dev, int max_blocks,
+                                 const int *positions_dev, RopeAppendTarget *out)
+{
+    int rc = check_pool_layer(pool, layer, "pool_rope_append_target");
+    if (rc != NVK_OK)
+        return rc;
+    if (!(rope_theta > 0.f) || !block_tables_dev || !positions_dev || max_blocks <= 0 || !out || pool->head_dim % 2 != 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "pool_rope_append_target: bad arguments");
+    nvk::DeviceScope scope(pool->device);
+    rc = ensure_rope_table(pool, rope_theta);
+    if (rc != NVK_OK)
+        return rc;
+    out->k_layer = pool->k_layer(layer), out->v_layer = pool->v_layer(layer);
+    out->block_tables = block_tables_dev, out->positions = positions_dev, out->inv_freq = pool->rope_inv_freq;
+    out->max_blocks = max_blocks, out->num_blocks = pool->num_blocks, out->block_size = pool->block_size;
+    out->head_dim = pool->head_dim, out->row_len = pool->row_len(), out->bs_magic = pool->bs_magic;
+    return NVK_OK;
+}
+
+extern "C" {
+
 int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const float *k_block, const float *v_block)
 {
     int rc = check_pool_layer(pool, layer, "nvk_pool_upload_block");

@@ -261,3 +261,56 @@ def test_layer_from_the_hidden_state():
             batch.end_step()
             for rid, c in zip(ids, chunks):
                 fed[rid] += c
+
+
+@pytest.mark.parametrize("n_req", [1, 2])
+def test_one_and_two_row_steps_fuse_rope_and_append_into_the_projection(n_req):
+    """With one or two decoding rows nvk_batch_layer_hidden runs the q/k/v projections, RoPE and the KV append as ONE
+    launch (the GEMV's epilogue writes where nvk_rope_append_kernel would).  Same arithmetic: the attention output
+    and every K/V block must equal, bit for bit, the piecewise path (nvk_qkv_project_device + nvk_batch_layer) run on
+    a second pool with the same history."""
+    L, H, KV, hd, bs, D = 2, 8, 2, 64, 8, 192
+    nb, max_blocks = 32, 8
+    rng = np.random.default_rng(92)
+    sc = np.float32(1.0 / np.sqrt(D))
+    W = [dict(g=rng.random(D, dtype=np.float32) + np.float32(0.5),
+              wq=rng.standard_normal((H * hd, D), dtype=np.float32) * sc,
+              wk=rng.standard_normal((KV * hd, D), dtype=np.float32) * sc,
+              wv=rng.standard_normal((KV * hd, D), dtype=np.float32) * sc) for _ in range(L)]
+    ids = list(range(1, n_req + 1))
+    prompt = [13, 6][:n_req]
+    xs = [[rng.standard_normal((sum(prompt) if s == 0 else n_req, D), dtype=np.float32) for _ in range(L)] for s in range(12)]
+    outs, caches = [], []
+    for fused in (True, False):
+        bm = nv.BlockManager(nb, bs)
+        with nv.PagedKVPool(L, nb, bs, KV, hd) as pool, nv.DecodeBatch(pool, bm, 2, max_blocks) as batch:
+            dW = [{k: DeviceArray(v) for k, v in w.items()} for w in W]
+            for rid in ids:
+                batch.add_request(rid)
+            got = []
+            for s in range(12):
+                chunks = prompt if s == 0 else [1] * n_req
+                rows = batch.begin_step_chunks(ids, chunks, H)
+                for layer in range(L):
+                    x, w = DeviceArray(xs[s][layer]), dW[layer]
+                    outd = DeviceArray(np.full((rows, H, hd), np.nan, np.float32))
+                    if fused or s == 0:
+                        batch.layer_hidden(layer, x, D, w["g"], w["wq"], w["wk"], w["wv"], outd, 10000.0)
+                    else:
+                        q = DeviceArray(np.zeros((rows, H * hd), np.float32))
+                        k = DeviceArray(np.zeros((rows, KV * hd), np.float32))
+                        v = DeviceArray(np.zeros((rows, KV * hd), np.float32))
+                        xb = DeviceArray(np.zeros((rows, D), np.float32))
+                        nv.qkv_project_device(q, k, v, x, xb, w["g"], w["wq"], w["wk"], w["wv"], rows, D, H * hd, KV * hd,
+                                              stream=pool.stream)
+                        batch.layer(layer, q, k, v, outd, 10000.0)
+                    pool.synchronize()
+                    got.append(outd.numpy().copy())
+                batch.end_step()
+            outs.append(got)
+            blocks = sorted(b for rid in ids for b in batch.request_blocks(rid))
+            caches.append([pool.download_block(layer, b) for layer in range(L) for b in blocks])
+    for a, b in zip(outs[0], outs[1]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    for (ka, va), (kb, vb) in zip(caches[0], caches[1]):
+        assert np.array_equal(ka, kb) and np.array_equal(va, vb)
