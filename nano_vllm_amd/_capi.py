@@ -135,6 +135,7 @@ SIGNATURES = {
     "nvk_model_request_len": (C.c_int, [_vp, C.c_int]),
     "nvk_model_free_blocks": (C.c_int, [_vp]),
     "nvk_model_use_graphs": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_use_linked_norms": (C.c_int, [_vp, C.c_int]),
     "nvk_model_step_chunks": (C.c_int, [_vp, _i, _i, _i, C.c_int, _i, _f]),
     "nvk_model_step": (C.c_int, [_vp, _i, _i, C.c_int, _i, _f]),
     "nvk_model_forward": (C.c_int, [_vp, C.c_int, C.c_int, _f]),

@@ -566,6 +566,80 @@ int nvk_batch_layer(nvk_batch *b, int layer, float *q_dev, const float *k_rows_d
     return nvk_decode_planned(b->pool, layer, b->plan, q_dev, b->d_tables, b->max_blocks, out_dev, (void *)st);
 }
 
+} // extern "C"
+
+namespace {
+
+// grow nvk_batch_layer_hidden's scratch rows (q / k / v / normalised x) to `rows` x the step's dimensions
+int reserve_hidden_rows(nvk_batch *b, int rows, int dim)
+{
+    const size_t qdim = (size_t)b->n_heads * b->head_dim;
+    if ((size_t)rows <= b->h_rows && (size_t)dim <= b->h_dim && qdim <= b->h_qdim)
+        return NVK_OK;
+    HIP_TRY(hipDeviceSynchronize()); // earlier launches may still use the old ones
+    for (float **p : {&b->h_q, &b->h_k, &b->h_v, &b->h_xb})
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    b->h_rows = b->h_dim = b->h_qdim = 0;
+    const size_t r = std::max((size_t)rows, (size_t)b->max_seqs), d = (size_t)dim;
+    HIP_TRY(hipMalloc((void **)&b->h_q, r * qdim * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&b->h_k, r * b->row_len * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&b->h_v, r * b->row_len * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&b->h_xb, r * d * sizeof(float)));
+    b->h_rows = r, b->h_dim = d, b->h_qdim = qdim;
+    return NVK_OK;
+}
+
+// every row of the step decodes, and they are few enough for the GEMV with the RoPE + append epilogue
+bool decode_rows_fuse(const nvk_batch *b, int rows, int dim, float rope_theta)
+{
+    const bool all_decode = !b->chunked || b->n_decode == (int)b->step_ids.size();
+    return all_decode && rope_theta > 0.f && b->head_dim % 2 == 0
+           && nvk::qkv_rope_append_ok(rows, dim, b->n_heads * b->head_dim, b->row_len);
+}
+
+// model.hpp:164-175, 190-207, 221 for such a step: q | k | v GEMV with the rotation and the append in its epilogue, then
+// the attention
+int project_rope_append_attend(nvk_batch *b, int layer, const float *act, int dim, const nvk::NormLink *link,
+                               const float *wq_dev, const float *wk_dev, const float *wv_dev, float *out_dev,
+                               float rope_theta, hipStream_t st)
+{
+    nvk::RopeAppendTarget target;
+    int rc = nvk::pool_rope_append_target(b->pool, layer, rope_theta, b->d_tables, b->max_blocks, b->d_pos, &target);
+    if (rc == NVK_OK)
+        rc = nvk::qkv_rope_append(target, b->h_q, act, wq_dev, wk_dev, wv_dev, nvk_batch_step_rows(b), dim,
+                                  b->n_heads * b->head_dim, b->device, (void *)st, link);
+    if (rc != NVK_OK)
+        return rc;
+    return nvk_decode_planned(b->pool, layer, b->plan, b->h_q, b->d_tables, b->max_blocks, out_dev, (void *)st);
+}
+
+} // namespace
+
+int nvk::batch_layer_hidden_linked(nvk_batch *b, int layer, const float *xg_dev, int dim, const NormLink &link,
+                                   const float *wq_dev, const float *wk_dev, const float *wv_dev, float *out_dev,
+                                   float rope_theta, void *stream)
+{
+    if (!b || !b->in_step || b->step_ids.empty() || !xg_dev || dim <= 0 || !wq_dev || !wk_dev || !wv_dev || !out_dev
+        || !link.ss_in)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "batch_layer_hidden_linked: bad arguments");
+    const int rows = nvk_batch_step_rows(b);
+    if (rows < 0)
+        return rows;
+    if (!decode_rows_fuse(b, rows, dim, rope_theta))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "batch_layer_hidden_linked: not a step of one or two decoding rows");
+    nvk::DeviceScope scope(b->device);
+    int              rc = reserve_hidden_rows(b, rows, dim);
+    if (rc != NVK_OK)
+        return rc;
+    return project_rope_append_attend(b, layer, xg_dev, dim, &link, wq_dev, wk_dev, wv_dev, out_dev, rope_theta,
+                                      stream_or_pool(b, stream));
+}
+
+extern "C" {
+
 int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim, const float *rms_weight_dev,
                            const float *wq_dev, const float *wk_dev, const float *wv_dev, float rms_eps, float *out_dev,
                            float rope_theta, void *stream)
@@ -582,27 +656,12 @@ int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim,
     const size_t qdim = (size_t)b->n_heads * b->head_dim;
     nvk::DeviceScope  scope(b->device);
     hipStream_t  st = stream_or_pool(b, stream);
-    if ((size_t)rows > b->h_rows || (size_t)dim > b->h_dim || qdim > b->h_qdim) {
-        // grow the scratch rows: earlier launches may still use the old ones
-        HIP_TRY(hipDeviceSynchronize());
-        for (float **p : {&b->h_q, &b->h_k, &b->h_v, &b->h_xb})
-            if (*p) {
-                (void)hipFree(*p);
-                *p = nullptr;
-            }
-        b->h_rows = b->h_dim = b->h_qdim = 0;
-        const size_t r = std::max((size_t)rows, (size_t)b->max_seqs), d = (size_t)dim;
-        HIP_TRY(hipMalloc((void **)&b->h_q, r * qdim * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&b->h_k, r * b->row_len * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&b->h_v, r * b->row_len * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&b->h_xb, r * d * sizeof(float)));
-        b->h_rows = r, b->h_dim = d, b->h_qdim = qdim;
-    }
+    int rc0 = reserve_hidden_rows(b, rows, dim);
+    if (rc0 != NVK_OK)
+        return rc0;
     // One or two decoding rows: the projections, the rotation and the append are one launch (the GEMV's epilogue
     // writes where nvk_rope_append_kernel would: same arithmetic, same bits, one kernel and two scratch rows less).
-    const bool all_decode = !b->chunked || b->n_decode == (int)b->step_ids.size();
-    if (all_decode && rope_theta > 0.f && b->head_dim % 2 == 0
-        && nvk::qkv_rope_append_ok(rows, dim, (int)qdim, b->row_len)) {
+    if (decode_rows_fuse(b, rows, dim, rope_theta)) {
         const float *act = x_dev;
         if (rms_weight_dev) { // model.hpp:161
             int rc = nvk_batch_rms_norm_device(b->h_xb, x_dev, rms_weight_dev, rows, dim, rms_eps, b->device, (void *)st);
@@ -610,13 +669,7 @@ int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim,
                 return rc;
             act = b->h_xb;
         }
-        nvk::RopeAppendTarget target;
-        int rc = nvk::pool_rope_append_target(b->pool, layer, rope_theta, b->d_tables, b->max_blocks, b->d_pos, &target);
-        if (rc == NVK_OK) // model.hpp:164-175, 190-207
-            rc = nvk::qkv_rope_append(target, b->h_q, act, wq_dev, wk_dev, wv_dev, rows, dim, (int)qdim, b->device, (void *)st);
-        if (rc != NVK_OK)
-            return rc;
-        return nvk_decode_planned(b->pool, layer, b->plan, b->h_q, b->d_tables, b->max_blocks, out_dev, (void *)st); // :221
+        return project_rope_append_attend(b, layer, act, dim, nullptr, wq_dev, wk_dev, wv_dev, out_dev, rope_theta, st);
     }
     // model.hpp:161-166: xb = rms_norm(x), q / k / v = wq / wk / wv . xb -- then :169-221 as nvk_batch_layer
     int rc = nvk_qkv_project_device(b->h_q, b->h_k, b->h_v, x_dev, b->h_xb, rms_weight_dev, wq_dev, wk_dev, wv_dev, rows,

@@ -23,6 +23,25 @@ struct RopeAppendTarget
     int          max_blocks, num_blocks, block_size, head_dim, row_len; // row_len = n_kv_heads * head_dim
     unsigned     bs_magic;
 };
+// ---- a norm carried from one GEMV to the next (one or two rows) --------------------------------
+// The residual add + RMSNorm between two projections without a kernel of its own.  The producer (wo, w_down) adds its
+// product to the residual stream and leaves xg = x * gain and, per 4-column tile, the sum of the four new squares
+// (ss_out, gain_out, xg_out set).  The consumer reads xg as its input rows and multiplies its product by 1 / rms,
+// rms from those partial sums (ss_in, ss_n set).  A few ulp from the separate norm (1 / rms after the dot product
+// instead of before); nothing else changes.
+struct NormLink
+{
+    const float *ss_in  = nullptr; // consumer: [rows, ss_n] partial sums of squares of the (un-gained) input rows
+    int          ss_n   = 0;
+    float        eps    = 0.f;
+    const float *gain_out = nullptr; // producer: the next norm's weight [out_dim]
+    float       *xg_out = nullptr;   // producer: [rows, out_dim]
+    float       *ss_out = nullptr;   // producer: [rows, ceil(out_dim / 4)]
+};
+// out = in . w0^T with the link applied (producer: out += ...; consumer: ... / rms); glu: silu(in . w0^T) * (in . w1^T)
+int linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in_dev, const float *w0_dev,
+                const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream);
+
 constexpr int kQkvRopeMaxRows = 2;
 int pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const int *block_tables_dev, int max_blocks,
                             const int *positions_dev, RopeAppendTarget *out);
@@ -30,7 +49,12 @@ int pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const i
 // (model.hpp:164-175, 190-207 in one launch; the arithmetic of the separate kernels, so the same bits).
 // rows <= kQkvRopeMaxRows.
 int qkv_rope_append(const RopeAppendTarget &target, float *q_dev, const float *x_dev, const float *wq_dev,
-                    const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream);
+                    const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream,
+                    const NormLink *link = nullptr);
+// nvk_batch_layer_hidden for one or two decoding rows whose input rows are a producer's xg (link: ss_in, ss_n, eps)
+int batch_layer_hidden_linked(nvk_batch *b, int layer, const float *xg_dev, int dim, const NormLink &link,
+                              const float *wq_dev, const float *wk_dev, const float *wv_dev, float *out_dev,
+                              float rope_theta, void *stream);
 bool qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim);
 
 } // namespace nvk

@@ -59,7 +59,7 @@
 #endif
 #ifndef NVK_GEMV_MAX_ROWS
 #define NVK_GEMV_MAX_ROWS 2 // up to here the vector-ALU GEMV kernel (measured: from 3 rows on its registers allow one
-                            // workgroup per CU and the MFMA kernel is as fast); at most 4, 0 switches it off
+                            // workgroup per CU and the MFMA kernel is as fast); at most 2, 0 switches it off
 #endif
 #ifndef NVK_SKINNY_TM
 #define NVK_SKINNY_TM 1 // 33-96 rows: one wave multiplies 2-3 row tiles by each weight tile (0: separate workgroups per row tile)
@@ -70,6 +70,8 @@
 #ifndef NVK_SKINNY_MAX_ROWS
 #define NVK_SKINNY_MAX_ROWS 96 // up to here the weight-streaming MFMA kernel (32-row tiles), above it the tiled one
 #endif
+
+static_assert(NVK_GEMV_MAX_ROWS >= 0 && NVK_GEMV_MAX_ROWS <= 2, "nvk_gemv_kernel is instantiated for one and two rows");
 
 namespace nvk {
 
@@ -98,6 +100,7 @@ struct LinearParams
     LinearSeg    seg[3];
     int          nseg, n_tiles, m_tiles;
     RopeAppendTarget rope; // nvk_gemv_kernel<.., ROPE>: where the q / k / v epilogue writes
+    NormLink         link; // nvk_gemv_kernel<.., SCALE / RESID>: the norm carried from one GEMV to the next
 };
 
 __device__ __forceinline__ const LinearSeg &segment_of(const LinearParams &p, int tile)
@@ -536,12 +539,21 @@ constexpr int kGemvWaves = 8, kGemvBK = 64;
 // ROPE (kGemvCols = 4, the three segments wq, wk, wv): the epilogue is nvk_rope_append_kernel -- q and k columns are
 // rotated in their pairs (both columns of a pair are in the workgroup's tile) by the row's position, q goes to the
 // first segment's output, k and v straight to the row's slot in the paged cache.  Same expressions, same bits.
-template <int M, int kGemvCols, int DEPTH, bool GLU = false, bool ROPE = false>
+//
+// The norm between two GEMVs without a kernel of its own (NormLink, nvk_internal.h):
+// RESID (a plain 4-column tile; the producer: wo, w_down): out = out + product (the residual add), and beside it
+// xg = out * gain (the next norm's gain, not yet its 1 / rms) and ss[tile] = the sum of squares of the tile's four new
+// values.  SCALE (the consumer: the input rows are such an xg): the product is multiplied by 1 / rms, rms from the
+// ss[] the producer left -- summed here by the whole workgroup in a fixed order while the weights stream.
+// out = rms * sum_k w[k] (x[k] g[k]) instead of sum_k w[k] ((x[k] rms) g[k]): a few ulp from the separate norm.
+template <int M, int kGemvCols, int DEPTH, bool GLU = false, bool ROPE = false, bool SCALE = false, bool RESID = false>
 __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearParams p)
 {
     static_assert(!GLU || kGemvCols == 4, "GLU pairs two gate rows with two up rows");
     static_assert(!ROPE || (kGemvCols == 4 && !GLU), "ROPE needs a rotation pair inside the tile");
+    static_assert(!RESID || (kGemvCols == 4 && !GLU && !ROPE && !SCALE && M * 4 <= 64), "RESID: a plain 4-column tile");
     __shared__ float s_red[kGemvWaves][M][kGemvCols];
+    __shared__ float s_ss[kGemvWaves][M];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane >> 4, lc = (lane & 15) * 4;
     // GLU: lane groups 0, 1 carry gate rows n0, n0 + 1, groups 2, 3 the same rows of up; `nt` is the tile the plain
@@ -599,6 +611,20 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
     for (int d = 0; d < DEPTH; d++)
         if (d < steps)
             fetch(ring[d], k_of(d));
+    // small operands of the epilogue, asked for now so that they are here when the product is
+    float ssq[M], old = 0.f, gain_n = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        ssq[m] = 0.f;
+        if (SCALE && m < p.m)
+            for (int i = tid; i < p.link.ss_n; i += 64 * kGemvWaves)
+                ssq[m] += p.link.ss_in[m * p.link.ss_n + i];
+    }
+    if (RESID && tid < M * kGemvCols) {
+        const int m = tid / kGemvCols, n = n0 + tid % kGemvCols;
+        if (m < p.m && n < sg.n)
+            old = sg.out[(int64_t)m * sg.ldo + n], gain_n = p.link.gain_out[n];
+    }
     for (int s = 0; s < steps; s += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++)
@@ -618,7 +644,26 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
             if ((lane & 15) == 0)
                 s_red[wave][m][lr + 4 * i] = v;
         }
+    if (SCALE) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            float v = ssq[m];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                v += __shfl_xor(v, o);
+            if (lane == 0)
+                s_ss[wave][m] = v;
+        }
+    }
     __syncthreads();
+    // SCALE: 1 / rms of row m (normalization.hpp:15-22 over the row the producer summed)
+    auto inv_rms = [&](int m) {
+        float sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < kGemvWaves; w++)
+            sq += s_ss[w][m];
+        return 1.0f / sqrtf(sq / p.k + p.link.eps);
+    };
     if (GLU) {
         if (tid < M * 2) {
             const int m = tid / 2, c = tid % 2;
@@ -626,6 +671,10 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
 #pragma unroll
             for (int w = 0; w < kGemvWaves; w++)
                 gate += s_red[w][m][c], up += s_red[w][m][c + 2];
+            if (SCALE) {
+                const float r = inv_rms(m);
+                gate *= r, up *= r;
+            }
             if (m < p.m && n0 + c < p.seg[0].n) {
 #pragma clang fp contract(off) // val = g / (1 + expf(-g)); val * up -- two roundings, as the separate kernel
                 const float val = gate / (1.0f + expf(-gate));
@@ -640,6 +689,10 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
 #pragma unroll
             for (int w = 0; w < kGemvWaves; w++)
                 sum += s_red[w][m][c], mate += s_red[w][m][c ^ 1];
+            if (SCALE) {
+                const float r = inv_rms(m);
+                sum *= r, mate *= r;
+            }
             const RopeAppendTarget &t  = p.rope;
             const int               si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
             const int               pos = m < p.m ? t.positions[m] : -1;
@@ -665,12 +718,34 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
             }
         }
     }
+    else if (RESID) {
+        if (tid < 64) { // the writers are threads 0 .. 4 M - 1; the whole first wave takes part in the shuffles
+            const int  m = min(tid / kGemvCols, M - 1), c = tid % kGemvCols;
+            const bool mine = tid < M * kGemvCols && m < p.m && n0 + c < sg.n;
+            float      sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < kGemvWaves; w++)
+                sum += s_red[w][m][c];
+            const float xn = mine ? old + sum : 0.f; // model.hpp:227-228 / 238-239
+            if (mine) {
+                sg.out[(int64_t)m * sg.ldo + n0 + c]         = xn;
+                p.link.xg_out[(int64_t)m * sg.ldo + n0 + c] = xn * gain_n;
+            }
+            // the tile's share of the next norm's sum of squares, in column order
+            const int   base = tid - c;
+            const float x0 = __shfl(xn, base), x1 = __shfl(xn, base + 1), x2 = __shfl(xn, base + 2), x3 = __shfl(xn, base + 3);
+            if (c == 0 && tid < M * kGemvCols && m < p.m)
+                p.link.ss_out[m * (int)gridDim.x + nt] = fmaf(x3, x3, fmaf(x2, x2, fmaf(x1, x1, x0 * x0)));
+        }
+    }
     else if (tid < M * kGemvCols) {
         const int m = tid / kGemvCols, c = tid % kGemvCols;
         float     sum = 0.f;
 #pragma unroll
         for (int w = 0; w < kGemvWaves; w++)
             sum += s_red[w][m][c];
+        if (SCALE)
+            sum *= inv_rms(m);
         if (m < p.m && n0 + c < sg.n)
             sg.out[(int64_t)m * sg.ldo + n0 + c] = sum;
     }
@@ -706,7 +781,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // One launch for up to three (weight, out, n) segments sharing the activations `in` [batch, in_dim].
 int launch_linear(const float *in, int batch, int in_dim, const float *const *w, float *const *out, const int *n,
                   int nseg, int device, hipStream_t st, const char *who, bool glu = false,
-                  const nvk::RopeAppendTarget *rope = nullptr)
+                  const nvk::RopeAppendTarget *rope = nullptr, const nvk::NormLink *link = nullptr)
 {
     if (in_dim % 4 != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: in_dim=%d must be a multiple of 4", who, in_dim);
@@ -728,6 +803,13 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the RoPE epilogue needs the GEMV and q, k, v segments", who);
     if (rope)
         p.rope = *rope;
+    const bool scale = link && link->ss_in, resid = link && link->ss_out;
+    if (link) {
+        if (!(gemv && NVK_GEMV_COLS == 4) || (scale && resid) || (resid && (glu || rope || nseg != 1))
+            || (scale && link->ss_n <= 0) || (resid && (!link->gain_out || !link->xg_out)) || !(link->eps >= 0.f))
+            return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: a norm link needs the GEMV (scale in, or residual out)", who);
+        p.link = *link;
+    }
     if (glu && !(gemv && NVK_GEMV_COLS == 4 && nseg == 2 && n[0] == n[1] && n[0] > 0))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the GLU form needs the GEMV and two equal segments", who);
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
@@ -770,22 +852,32 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     if (gemv) {
         p.m_tiles = 1;
         const dim3 grid((unsigned)(glu ? (n[0] + 1) / 2 : tiles)), block(64 * nvk::kGemvWaves);
-        if (glu && batch == 1)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, 4, NVK_GEMV_DEPTH, true>), grid, block, 0, st, p);
+#define NVK_GEMV_LAUNCH(M_, COLS_, ...) \
+    hipLaunchKernelGGL((nvk::nvk_gemv_kernel<M_, COLS_, NVK_GEMV_DEPTH, __VA_ARGS__>), grid, block, 0, st, p)
+#define NVK_GEMV_ROWS(COLS_, ...)                    \
+    do {                                             \
+        if (batch == 1)                              \
+            NVK_GEMV_LAUNCH(1, COLS_, __VA_ARGS__);  \
+        else                                         \
+            NVK_GEMV_LAUNCH(2, COLS_, __VA_ARGS__);  \
+    } while (0)
+        //                 GLU    ROPE   SCALE  RESID
+        if (glu && scale)
+            NVK_GEMV_ROWS(4, true, false, true, false);
         else if (glu)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, 4, NVK_GEMV_DEPTH, true>), grid, block, 0, st, p);
-        else if (rope && batch == 1)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, 4, NVK_GEMV_DEPTH, false, true>), grid, block, 0, st, p);
+            NVK_GEMV_ROWS(4, true, false, false, false);
+        else if (rope && scale)
+            NVK_GEMV_ROWS(4, false, true, true, false);
         else if (rope)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, 4, NVK_GEMV_DEPTH, false, true>), grid, block, 0, st, p);
-        else if (batch == 1)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<1, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
-        else if (batch == 2)
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<2, NVK_GEMV_COLS, NVK_GEMV_DEPTH>), grid, block, 0, st, p);
-#if NVK_GEMV_MAX_ROWS > 2
+            NVK_GEMV_ROWS(4, false, true, false, false);
+        else if (resid)
+            NVK_GEMV_ROWS(4, false, false, false, true);
+        else if (scale)
+            NVK_GEMV_ROWS(4, false, false, true, false);
         else
-            hipLaunchKernelGGL((nvk::nvk_gemv_kernel<4, 32, 2>), grid, block, 0, st, p);
-#endif
+            NVK_GEMV_ROWS(NVK_GEMV_COLS, false, false, false, false);
+#undef NVK_GEMV_ROWS
+#undef NVK_GEMV_LAUNCH
     }
     else if (skinny) {
         // 16 x 16 tiles up to 16 rows; 32 x 32 up to 32; above, one wave carries 2 or 3 row tiles of 32 (NVK_SKINNY_TM)
@@ -853,8 +945,27 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
 
 } // namespace
 
+int nvk::linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in_dev, const float *w0_dev,
+                     const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream)
+{
+    if (rows < 1 || rows > kQkvRopeMaxRows || !out_dev || !in_dev || !w0_dev || (glu && !w1_dev) || in_dim <= 0 || out_dim <= 0)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "linked_gemv: bad arguments");
+    if (rows == 2 && (glu ? 2LL : 1LL) * out_dim > NVK_GEMV2_MAX_COLS)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "linked_gemv: two rows of %d columns are not a GEMV", out_dim);
+    int rc = check_device(device, "linked_gemv");
+    if (rc != NVK_OK)
+        return rc;
+    nvk::DeviceScope   scope(device);
+    const float *const w[2]   = {w0_dev, w1_dev};
+    float *const       out[2] = {out_dev, out_dev};
+    const int          n[2]   = {out_dim, out_dim};
+    return launch_linear(in_dev, rows, in_dim, w, out, n, glu ? 2 : 1, device, (hipStream_t)stream, "linked_gemv", glu,
+                         nullptr, &link);
+}
+
 int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x_dev, const float *wq_dev,
-                         const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream)
+                         const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream,
+                         const NormLink *link)
 {
     if (rows < 1 || rows > kQkvRopeMaxRows || rows > NVK_GEMV_MAX_ROWS || NVK_GEMV_COLS != 4 || dim <= 0 || q_dim <= 0
         || !q_dev || !x_dev || !wq_dev || !wk_dev || !wv_dev || t.head_dim <= 0 || t.head_dim % 2 != 0
@@ -870,7 +981,7 @@ int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x
     const float *const w[3]   = {wq_dev, wk_dev, wv_dev};
     float *const       out[3] = {q_dev, q_dev, q_dev}; // k and v go to the cache
     const int          n[3]   = {q_dim, t.row_len, t.row_len};
-    return launch_linear(x_dev, rows, dim, w, out, n, 3, device, (hipStream_t)stream, "qkv_rope_append", false, &t);
+    return launch_linear(x_dev, rows, dim, w, out, n, 3, device, (hipStream_t)stream, "qkv_rope_append", false, &t, link);
 }
 
 // can rows x (q_dim + 2 kv_dim) go through qkv_rope_append?

@@ -145,6 +145,7 @@ struct nvk_model
     // while nothing it bakes in has changed: with few requests a step is hundreds of short dependent kernels and
     // the launch gaps, not the kernels, set its time.
     bool            use_graphs = true;
+    bool            use_linked = true; // single-row steps: the norms ride between the GEMVs (nvk::NormLink)
     int             graph_failures = 0;
     hipGraphExec_t  graph_exec = nullptr;
     long long       graph_sig[9] = {0};
@@ -390,6 +391,18 @@ int nvk_model_request_len(const nvk_model *m, int request_id)
     return nvk_batch_request_len(m->batch, request_id);
 }
 
+int nvk_model_use_linked_norms(nvk_model *m, int on)
+{
+    if (!m)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_use_linked_norms: null model");
+    m->use_linked = on != 0;
+    if (m->graph_exec) { // recorded with the other sequence of kernels
+        (void)hipGraphExecDestroy(m->graph_exec);
+        m->graph_exec = nullptr;
+    }
+    return NVK_OK;
+}
+
 int nvk_model_use_graphs(nvk_model *m, int on)
 {
     if (!m)
@@ -457,7 +470,54 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
         return code;
     };
     // everything between the batch's bookkeeping and the host's wait: tokens in, embedding .. sampler, next tokens out
-    auto enqueue_body = [&]() -> int {
+    // One decoding row (the reference's own case): 6 launches per layer instead of 8.  The residual adds sit in the
+    // epilogues of the wo and w_down GEMVs, which also leave x * gain and the partial sums of squares for the next
+    // norm; the GEMV that consumes them multiplies its product by 1 / rms (nvk::NormLink).  xn holds x * gain, xb the
+    // partial sums.  Layer 0's first norm has no producer and stays a kernel.
+    const bool linked = m->use_linked && R == 1 && n == 1;
+    auto enqueue_linked = [&]() -> int {
+        hipError_t e1 = hipMemcpyAsync(m->tokens_dev, h_tok, sizeof(int), hipMemcpyHostToDevice, st);
+        if (e1 != hipSuccess)
+            return nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: staging the tokens failed: %s", hipGetErrorString(e1));
+        hipLaunchKernelGGL(nvk_embed_kernel, dim3(1), dim3(64), 0, st, m->x, m->tok_emb, m->tokens_dev, D, V);
+        const int tiles_d = (D + 3) / 4;
+        auto      produce = [&](const float *gain) { // x += in . w^T; xn = x * gain; xb = partial sums of x^2
+            nvk::NormLink l;
+            l.gain_out = gain, l.xg_out = m->xn, l.ss_out = m->xb, l.eps = m->rms_eps;
+            return l;
+        };
+        nvk::NormLink consume; // ... / rms(x), x as the last producer left it
+        consume.ss_in = m->xb, consume.ss_n = tiles_d, consume.eps = m->rms_eps;
+        int r2 = NVK_OK;
+        for (int l = 0; l < m->n_layers && r2 == NVK_OK; l++) {
+            const LayerWeights &w = m->layers[(size_t)l];
+            if (l == 0) // model.hpp:161-221
+                r2 = nvk_batch_layer_hidden(m->batch, l, m->x, D, w.rms_att, w.wq, w.wk, w.wv, m->rms_eps, m->att,
+                                            m->rope_theta, (void *)st);
+            else
+                r2 = nvk::batch_layer_hidden_linked(m->batch, l, m->xn, D, consume, w.wq, w.wk, w.wv, m->att, m->rope_theta,
+                                                    (void *)st);
+            if (r2 == NVK_OK) // :224, :227-228 and the operands of :231
+                r2 = nvk::linked_gemv(produce(w.rms_ffn), false, m->x, m->att, w.wo, nullptr, 1, QD, D, m->device, (void *)st);
+            if (r2 == NVK_OK) // :231-234
+                r2 = nvk::linked_gemv(consume, true, m->hb, m->xn, w.w_gate, w.w_up, 1, D, Hd, m->device, (void *)st);
+            if (r2 == NVK_OK) // :235, :238-239 and the operands of the next norm (the next layer's :161, or :243)
+                r2 = nvk::linked_gemv(produce(l + 1 < m->n_layers ? m->layers[(size_t)l + 1].rms_att : m->rms_final), false,
+                                      m->x, m->hb, w.w_down, nullptr, 1, Hd, D, m->device, (void *)st);
+        }
+        if (r2 == NVK_OK) // :243-246
+            r2 = nvk::linked_gemv(consume, false, m->logits, m->xn, m->lm_head, nullptr, 1, D, V, m->device, (void *)st);
+        if (r2 != NVK_OK)
+            return r2;
+        hipLaunchKernelGGL(nvk_argmax_kernel, dim3(1), dim3(kArgmaxThreads), 0, st, m->next_dev, m->logits, V);
+        hipError_t e2 = hipGetLastError();
+        if (e2 == hipSuccess)
+            e2 = hipMemcpyAsync(h_next, m->next_dev, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e2 != hipSuccess)
+            return nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: %s", hipGetErrorString(e2));
+        return NVK_OK;
+    };
+    auto enqueue_plain = [&]() -> int {
         hipError_t e1 = hipMemcpyAsync(m->tokens_dev, h_tok, (size_t)R * sizeof(int), hipMemcpyHostToDevice, st);
         if (e1 == hipSuccess)
             e1 = hipMemcpyAsync(m->last_rows_dev, h_last, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st);
@@ -514,6 +574,8 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
             return nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: %s", hipGetErrorString(e2));
         return NVK_OK;
     };
+
+    auto enqueue_body = [&]() -> int { return linked ? enqueue_linked() : enqueue_plain(); };
 
     bool replayed = false;
     if (m->use_graphs && R == n) { // a pure decode step

@@ -59,6 +59,10 @@ class LlamaModel:
         """Replay pure decode steps as a hipGraph (default) or launch every kernel directly; same results."""
         _capi.check(_capi.lib.nvk_model_use_graphs(self._h, int(bool(on))))
 
+    def use_linked_norms(self, on: bool) -> None:
+        """Single-row steps carry their norms between the GEMVs (default) or run them as kernels (a few ulp apart)."""
+        _capi.check(_capi.lib.nvk_model_use_linked_norms(self._h, int(bool(on))))
+
     @property
     def free_blocks(self) -> int:
         return int(_capi.lib.nvk_model_free_blocks(self._h))

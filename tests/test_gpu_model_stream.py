@@ -213,3 +213,37 @@ def test_graph_replay_gives_the_bits_of_direct_launches(spec, n_requests, checkp
             runs[graphs] = np.stack(got)
     assert np.isfinite(runs[False]).all()
     assert np.array_equal(runs[True], runs[False])
+
+
+@pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])
+def test_norms_carried_between_the_gemvs(spec, checkpoints):
+    """A single-row step carries its RMSNorms between the GEMVs (nvk_model_use_linked_norms: the producer leaves
+    x * gain and partial sums of squares, the consumer multiplies its product by 1 / rms).  Against the norms as
+    kernels the logits agree 10x tighter than the bar the whole model is held to against the reference (teacher
+    forced, step by step), with and without the graph; the graph does not change a bit."""
+    import nano_vllm_amd as nv
+
+    rng = np.random.default_rng(12)
+    prompt = [1] + rng.integers(3, spec["vocab_size"], size=6).tolist()
+    steps = min(30, spec["max_seq_len"] - 10)
+    runs, fed = {}, None
+    for linked, graphs in ((False, False), (True, False), (True, True)):
+        with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"]) as m:
+            m.use_linked_norms(linked)
+            m.use_graphs(graphs)
+            m.add_request(5)
+            nxt, logits = m.step_chunks([5], [prompt], True)
+            got, toks = [logits.copy()], [nxt.tolist()]
+            for i in range(steps):
+                nxt, logits = m.step([5], fed[i] if fed else nxt.tolist(), True)
+                got.append(logits.copy())
+                toks.append(nxt.tolist())
+            if fed is None:
+                fed = toks
+            runs[(linked, graphs)] = np.stack(got)
+    base = runs[(False, False)]
+    assert np.isfinite(base).all()
+    assert np.array_equal(runs[(True, True)], runs[(True, False)])
+    err = np.abs(runs[(True, False)] - base)
+    assert np.all(err <= 2e-4 + 1e-5 * np.abs(base)), float(err.max())
+    assert (runs[(True, False)].argmax(-1) == base.argmax(-1)).all()
