@@ -39,7 +39,8 @@ struct NormLink
     float       *ss_out = nullptr;   // producer: [rows, ceil(out_dim / 4)]
 };
 // out = in . w0^T with the link applied (producer: out += ...; consumer: ... / rms); glu: silu(in . w0^T) * (in . w1^T)
-int linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in_dev, const float *w0_dev,
+bool linked_gemv_ok(); // false in a build whose GEMV geometry has no linked form (NVK_GEMV_COLS != 4)
+int  linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in_dev, const float *w0_dev,
                 const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream);
 
 constexpr int kQkvRopeMaxRows = 2;

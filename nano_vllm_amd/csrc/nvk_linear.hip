@@ -797,7 +797,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     long long cols = 0;
     for (int s = 0; s < nseg; s++)
         cols += n[s];
-    const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS);
+    // (a norm link exists only in the GEMV: two linked rows stay there at any width)
+    const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS || link);
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
     if (rope && !(gemv && NVK_GEMV_COLS == 4 && nseg == 3 && !glu))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the RoPE epilogue needs the GEMV and q, k, v segments", who);
@@ -945,13 +946,14 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
 
 } // namespace
 
+bool nvk::linked_gemv_ok() { return NVK_GEMV_COLS == 4 && NVK_GEMV_MAX_ROWS >= 1; }
+
 int nvk::linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in_dev, const float *w0_dev,
                      const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream)
 {
-    if (rows < 1 || rows > kQkvRopeMaxRows || !out_dev || !in_dev || !w0_dev || (glu && !w1_dev) || in_dim <= 0 || out_dim <= 0)
+    if (rows < 1 || rows > NVK_GEMV_MAX_ROWS || !out_dev || !in_dev || !w0_dev || (glu && !w1_dev) || in_dim <= 0
+        || out_dim <= 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "linked_gemv: bad arguments");
-    if (rows == 2 && (glu ? 2LL : 1LL) * out_dim > NVK_GEMV2_MAX_COLS)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "linked_gemv: two rows of %d columns are not a GEMV", out_dim);
     int rc = check_device(device, "linked_gemv");
     if (rc != NVK_OK)
         return rc;

@@ -215,27 +215,30 @@ def test_graph_replay_gives_the_bits_of_direct_launches(spec, n_requests, checkp
     assert np.array_equal(runs[True], runs[False])
 
 
+@pytest.mark.parametrize("n_req", [1, 2])
 @pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])
-def test_norms_carried_between_the_gemvs(spec, checkpoints):
-    """A single-row step carries its RMSNorms between the GEMVs (nvk_model_use_linked_norms: the producer leaves
-    x * gain and partial sums of squares, the consumer multiplies its product by 1 / rms).  Against the norms as
-    kernels the logits agree 10x tighter than the bar the whole model is held to against the reference (teacher
-    forced, step by step), with and without the graph; the graph does not change a bit."""
+def test_norms_carried_between_the_gemvs(spec, n_req, checkpoints):
+    """A step of one or two decoding rows carries its RMSNorms between the GEMVs (nvk_model_use_linked_norms: the
+    producer leaves x * gain and partial sums of squares, the consumer multiplies its product by 1 / rms).  Against
+    the norms as kernels the logits agree 10x tighter than the bar the whole model is held to against the reference
+    (teacher forced, step by step), with and without the graph; the graph does not change a bit."""
     import nano_vllm_amd as nv
 
     rng = np.random.default_rng(12)
-    prompt = [1] + rng.integers(3, spec["vocab_size"], size=6).tolist()
+    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=k).tolist() for k in (6, 3)][:n_req]
+    ids = [5, 9][:n_req]
     steps = min(30, spec["max_seq_len"] - 10)
     runs, fed = {}, None
     for linked, graphs in ((False, False), (True, False), (True, True)):
-        with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"]) as m:
+        with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"], max_seqs=2) as m:
             m.use_linked_norms(linked)
             m.use_graphs(graphs)
-            m.add_request(5)
-            nxt, logits = m.step_chunks([5], [prompt], True)
+            for r in ids:
+                m.add_request(r)
+            nxt, logits = m.step_chunks(ids, prompts, True)
             got, toks = [logits.copy()], [nxt.tolist()]
             for i in range(steps):
-                nxt, logits = m.step([5], fed[i] if fed else nxt.tolist(), True)
+                nxt, logits = m.step(ids, fed[i] if fed else nxt.tolist(), True)
                 got.append(logits.copy())
                 toks.append(nxt.tolist())
             if fed is None:
