@@ -402,7 +402,7 @@ int nvk_model_free_blocks(const nvk_model *model);
 /* Pure decode steps replay a hipGraph of their ~12 launches per layer (captured again whenever the batch, the launch
  * shape or a scratch address changes); on by default, results are the same bits either way.  0 switches it off. */
 int nvk_model_use_graphs(nvk_model *model, int on);
-/* A step of one or two decoding rows (the reference's own case is one: bound by launch latency, not by HBM) carries its norms between
+/* A step of up to 16 decoding rows (the reference's own case is one: bound by launch latency, not by HBM) carries its norms between
  * the GEMVs instead of running them as kernels: the wo / w_down GEMVs add their product to the residual stream and
  * leave x * gain and partial sums of squares, the GEMV that follows multiplies its product by 1 / rms (6 launches per
  * layer instead of 8).  1 / rms after the dot product instead of before it: a few ulp from the separate norm, inside

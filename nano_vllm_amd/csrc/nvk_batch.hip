@@ -596,7 +596,7 @@ int reserve_hidden_rows(nvk_batch *b, int rows, int dim)
 bool decode_rows_fuse(const nvk_batch *b, int rows, int dim, float rope_theta)
 {
     const bool all_decode = !b->chunked || b->n_decode == (int)b->step_ids.size();
-    return all_decode && rope_theta > 0.f && b->head_dim % 2 == 0
+    return all_decode && rope_theta > 0.f && b->head_dim % 2 == 0 && (rows <= 2 || b->head_dim % 4 == 0)
            && nvk::qkv_rope_append_ok(rows, dim, b->n_heads * b->head_dim, b->row_len);
 }
 

@@ -36,14 +36,17 @@ struct NormLink
     float        eps    = 0.f;
     const float *gain_out = nullptr; // producer: the next norm's weight [out_dim]
     float       *xg_out = nullptr;   // producer: [rows, out_dim]
-    float       *ss_out = nullptr;   // producer: [rows, ceil(out_dim / 4)]
+    float       *ss_out = nullptr;   // producer: [rows, ss_out_n], ss_out_n = out_dim / 4 (filled in by linked_gemv)
+    int          ss_out_n = 0;
 };
 // out = in . w0^T with the link applied (producer: out += ...; consumer: ... / rms); glu: silu(in . w0^T) * (in . w1^T)
+int  linked_ss_n(int rows, int dim); // how many partial sums per row a producer of `dim` columns leaves
 bool linked_gemv_ok(); // false in a build whose GEMV geometry has no linked form (NVK_GEMV_COLS != 4)
 int  linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in_dev, const float *w0_dev,
-                const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream);
+                const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream,
+                float *scratch_dev = nullptr); // glu with more than two rows: [rows, out_dim], contents unspecified after
 
-constexpr int kQkvRopeMaxRows = 2;
+constexpr int kFusedRowsMax = 16; // the GEMV (1-2 rows) and the 16-row MFMA kernel carry the fused epilogues
 int pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const int *block_tables_dev, int max_blocks,
                             const int *positions_dev, RopeAppendTarget *out);
 // q_dev [rows, q_dim] = rope(wq . x); rope(wk . x) and wv . x go straight to the cache slots of the rows' positions

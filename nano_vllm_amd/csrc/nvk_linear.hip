@@ -368,9 +368,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32 -- half the MFMA cycles spent on padding rows, twice the workgroups, half the LDS.
 // TM > 1 (T = 32 only): one wave multiplies TM row tiles by the same weight tile, so up to 32 * TM rows still stream
 // the weights once; BK is then 32 so that the waves' private LDS regions fit.
-template <int T, int TM, int BK>
+// EPI / SCALE (T = 16, TM = 1: up to 16 rows): the epilogues of nvk_gemv_kernel for decode steps of a few requests --
+// kSkinnyResid and SCALE are the two ends of a NormLink, kSkinnyGlu is SwiGLU (the tile is 8 gate rows + the same 8
+// rows of up, 8 output columns), kSkinnyRope is RoPE + KV append.  See nvk_gemv_kernel and nvk_internal.h.
+enum { kSkinnyPlain = 0, kSkinnyResid = 1, kSkinnyGlu = 2, kSkinnyRope = 3 };
+
+template <int T, int TM, int BK, int EPI = kSkinnyPlain, bool SCALE = false>
 __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
 {
+    static_assert((EPI == kSkinnyPlain && !SCALE) || (T == 16 && TM == 1 && BK == 64), "epilogues: the 16-row kernel");
+    __shared__ float s_ssq[16]; // SCALE: every row's sum of squares
+    constexpr bool GLU = EPI == kSkinnyGlu;
     constexpr int LDS = BK + 4;             // row stride in LDS (floats)
     constexpr int LPR = BK / 4, RPI = 64 / LPR; // lanes per tile row, rows per load instruction
     constexpr int RW = T / RPI, RX = TM * T / RPI; // float4 per lane per step: weights, activations
@@ -381,8 +389,8 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     const int m0   = rem / 8 * (TM * T);
     if (nt >= p.n_tiles)
         return;
-    const LinearSeg sg = segment_of(p, nt);
-    const int       n0 = (nt - sg.tile0) * T;
+    const LinearSeg sg = GLU ? p.seg[0] : segment_of(p, nt);
+    const int       n0 = GLU ? nt * 8 : (nt - sg.tile0) * T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & (T - 1), part = lane / T; // MFMA operand row / column, and which k lanes of the instruction
     const int lr = lane / LPR, lc = (lane % LPR) * 4;
@@ -394,14 +402,16 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     for (int i = 0; i < RX; i++)
         aoff[i] = min(m0 + lr + RPI * i, p.m - 1) * p.lda + lc;
 #pragma unroll
-    for (int i = 0; i < RW; i++)
-        woff[i] = min(n0 + lr + RPI * i, sg.n - 1) * p.k + lc;
+    for (int i = 0; i < RW; i++) // GLU: operand rows 0-7 are gate rows n0 .., rows 8-15 the same rows of up
+        woff[i] = min(n0 + (GLU ? (lr + RPI * i) & 7 : lr + RPI * i), sg.n - 1) * p.k + lc;
     float4 rx[RX], rw0[RW], rw1[RW];
     auto   fetch_w = [&](float4(&r)[RW], int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
-        for (int i = 0; i < RW; i++)
-            r[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < RW; i++) {
+            const float *base = GLU && RPI * i >= 8 ? p.seg[1].w : sg.w; // (RPI = 4: uniform in i)
+            r[i] = inside ? load_stream(base + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     auto fetch_x = [&](int k0) {
         const bool inside = k0 + lc < p.k;
@@ -466,6 +476,29 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     }
     if (steps > 1)
         fetch_w(rw1, k_of(1));
+    // small operands of the epilogue, asked for now so that they are here when the product is
+    // (SCALE: the rows' sums of squares go to LDS right away -- registers held across the main loop would cost the second
+    //  workgroup of the CU.  32 threads a row, each a few of the producer's per-tile partial sums.)
+    float4 old4 = make_float4(0.f, 0.f, 0.f, 0.f), gain4 = old4;
+    if (SCALE) {
+        const int row = tid >> 5, sub = tid & 31; // 512 threads: rows 0 .. 15
+        float     v   = 0.f;
+        if (row < p.m)
+            for (int i = sub; i < p.link.ss_n; i += 32)
+                v += p.link.ss_in[row * p.link.ss_n + i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+            v += __shfl_xor(v, o);
+        if (sub == 0)
+            s_ssq[row] = v;
+    }
+    if (EPI == kSkinnyResid && tid < 64) {
+        const int l4 = (tid & 15) * 4, row = m0 + 4 * (l4 / T) + (tid >> 4), col = n0 + (l4 & (T - 1));
+        if (row < p.m && col + 3 < sg.n) {
+            old4  = *reinterpret_cast<const float4 *>(sg.out + (int64_t)row * sg.ldo + col);
+            gain4 = *reinterpret_cast<const float4 *>(p.link.gain_out + col);
+        }
+    }
     for (int s = 0; s < steps; s += 2) {
         stash(rw0);
         if (s + 2 < steps)
@@ -494,6 +527,89 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
         for (int r = 0; r < NACC; r++)
             sa[(t * NACC + r) * 64 + lane] = T == 32 ? acc32[t][r] : acc16[r & 3]; // own region: operand reads are behind us
     __syncthreads();
+    if (EPI != kSkinnyPlain || SCALE) { // T = 16, TM = 1: thread (r, l4) owns row 4 * (l4 / 16) + r, columns (l4 % 16) .. + 3
+        if (tid < 64) {
+            const int r = tid >> 4, l4 = (tid & 15) * 4, cg = l4 & 15;
+            const int row = m0 + 4 * (l4 / T) + r;
+            auto      total = [&](int at) {
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int w = 0; w < kSkinnyWaves; w++) {
+                    const float4 v = *reinterpret_cast<const float4 *>(s_mem + w * kRegion + r * 64 + at);
+                    sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+                }
+                return sum;
+            };
+            float4 sum = total(l4);
+            float  rms = 1.f;
+            if (SCALE) { // normalization.hpp:15-22 over the row the producer summed
+                rms = 1.0f / sqrtf(s_ssq[min(row, 15)] / p.k + p.link.eps);
+                sum.x *= rms, sum.y *= rms, sum.z *= rms, sum.w *= rms;
+            }
+            const int  col   = n0 + cg;
+            const bool whole = row < p.m && col + 3 < sg.n; // (the host checked n % 4 == 0: a float4 is in or out)
+            if (EPI == kSkinnyPlain) {
+                if (whole)
+                    *reinterpret_cast<float4 *>(sg.out + (int64_t)row * sg.ldo + col) = sum;
+            }
+            else if (EPI == kSkinnyResid) {
+                if (whole) { // model.hpp:227-228 / 238-239, and the next norm's operands
+                    const float4 xn = make_float4(old4.x + sum.x, old4.y + sum.y, old4.z + sum.z, old4.w + sum.w);
+                    *reinterpret_cast<float4 *>(sg.out + (int64_t)row * sg.ldo + col) = xn;
+                    *reinterpret_cast<float4 *>(p.link.xg_out + (int64_t)row * sg.ldo + col) =
+                        make_float4(xn.x * gain4.x, xn.y * gain4.y, xn.z * gain4.z, xn.w * gain4.w);
+                }
+                // the 16-column tile's share of the row's next sum of squares: the four threads of a row are neighbours
+                float v = whole ? fmaf(old4.w + sum.w, old4.w + sum.w, fmaf(old4.z + sum.z, old4.z + sum.z,
+                                       fmaf(old4.y + sum.y, old4.y + sum.y, (old4.x + sum.x) * (old4.x + sum.x)))) : 0.f;
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                if (cg == 0 && row < p.m && col < sg.n)
+                    p.link.ss_out[row * p.link.ss_out_n + col / 16] = v;
+            }
+            else if (EPI == kSkinnyGlu) {
+                if (cg < 8) { // gate in operand columns 0-7, up in 8-15 of the same rows
+                    float4 up = total(l4 + 8);
+                    up.x *= rms, up.y *= rms, up.z *= rms, up.w *= rms;
+                    if (whole) {
+#pragma clang fp contract(off) // silu(g) * u as the separate kernel (activation.hpp:34-40)
+                        float4 o;
+                        o.x = sum.x / (1.0f + expf(-sum.x)) * up.x, o.y = sum.y / (1.0f + expf(-sum.y)) * up.y;
+                        o.z = sum.z / (1.0f + expf(-sum.z)) * up.z, o.w = sum.w / (1.0f + expf(-sum.w)) * up.w;
+                        *reinterpret_cast<float4 *>(sg.out + (int64_t)row * sg.ldo + col) = o;
+                    }
+                }
+            }
+            else if (whole) { // kSkinnyRope: nvk_rope_append_kernel's arithmetic on the row's q / k / v columns
+                const RopeAppendTarget &t  = p.rope;
+                const int               si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
+                const int               pos = t.positions[row];
+                if (pos >= 0) {
+                    float4 o = sum;
+                    if (si < 2) {
+                        const int   pr = (col % t.head_dim) >> 1, pr1 = ((col + 2) % t.head_dim) >> 1;
+                        const float a0 = (float)pos * t.inv_freq[pr], a1 = (float)pos * t.inv_freq[pr1];
+                        double      s0, c0, s1, c1;
+                        sincos((double)a0, &s0, &c0);
+                        sincos((double)a1, &s1, &c1);
+                        const float2 p0 = rope_rotate(make_float2(sum.x, sum.y), make_float2((float)c0, (float)s0));
+                        const float2 p1 = rope_rotate(make_float2(sum.z, sum.w), make_float2((float)c1, (float)s1));
+                        o               = make_float4(p0.x, p0.y, p1.x, p1.y);
+                    }
+                    if (si == 0)
+                        *reinterpret_cast<float4 *>(sg.out + (int64_t)row * sg.ldo + col) = o;
+                    else {
+                        const int     blk = token_block(pos, t.bs_magic);
+                        const int     off = token_offset(pos, blk, t.block_size);
+                        const int     pb  = clamp_block(t.block_tables[(int64_t)row * t.max_blocks + blk], t.num_blocks);
+                        const int64_t at  = ((int64_t)pb * t.block_size + off) * t.row_len + col;
+                        *reinterpret_cast<float4 *>((si == 1 ? t.k_layer : t.v_layer) + at) = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (tid < NACC * 16) {
         const int r = tid >> 4, l4 = (tid & 15) * 4; // register r, lanes l4 .. l4 + 3
         const int pt = l4 / T;                        // the four lanes share a part
@@ -735,7 +851,7 @@ __global__ void __launch_bounds__(64 * kGemvWaves) nvk_gemv_kernel(const LinearP
             const int   base = tid - c;
             const float x0 = __shfl(xn, base), x1 = __shfl(xn, base + 1), x2 = __shfl(xn, base + 2), x3 = __shfl(xn, base + 3);
             if (c == 0 && tid < M * kGemvCols && m < p.m)
-                p.link.ss_out[m * (int)gridDim.x + nt] = fmaf(x3, x3, fmaf(x2, x2, fmaf(x1, x1, x0 * x0)));
+                p.link.ss_out[m * p.link.ss_out_n + nt] = fmaf(x3, x3, fmaf(x2, x2, fmaf(x1, x1, x0 * x0)));
         }
     }
     else if (tid < M * kGemvCols) {
@@ -800,18 +916,28 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     // (a norm link exists only in the GEMV: two linked rows stay there at any width)
     const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS || link);
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
-    if (rope && !(gemv && NVK_GEMV_COLS == 4 && nseg == 3 && !glu))
+    if ((rope || glu || link) && !gemv && !(batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: no fused epilogue for %d rows", who, batch);
+    if ((rope || glu || link) && !gemv) {
+        for (int s = 0; s < nseg; s++)
+            if (n[s] % 4 != 0)
+                return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: fused epilogues need out_dim %% 4 == 0", who);
+        if (rope && rope->head_dim % 4 != 0)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the RoPE epilogue needs head_dim %% 4 == 0", who);
+    }
+    if (rope && !(((gemv && NVK_GEMV_COLS == 4) || !gemv) && nseg == 3 && !glu))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the RoPE epilogue needs the GEMV and q, k, v segments", who);
     if (rope)
         p.rope = *rope;
     const bool scale = link && link->ss_in, resid = link && link->ss_out;
+    const bool fused16 = !gemv && batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16; // the 16-row MFMA kernel
     if (link) {
-        if (!(gemv && NVK_GEMV_COLS == 4) || (scale && resid) || (resid && (glu || rope || nseg != 1))
+        if (!((gemv && NVK_GEMV_COLS == 4) || fused16) || (scale && resid) || (resid && (glu || rope || nseg != 1))
             || (scale && link->ss_n <= 0) || (resid && (!link->gain_out || !link->xg_out)) || !(link->eps >= 0.f))
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: a norm link needs the GEMV (scale in, or residual out)", who);
         p.link = *link;
     }
-    if (glu && !(gemv && NVK_GEMV_COLS == 4 && nseg == 2 && n[0] == n[1] && n[0] > 0))
+    if (glu && !(((gemv && NVK_GEMV_COLS == 4) || !gemv) && nseg == 2 && n[0] == n[1] && n[0] > 0))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the GLU form needs the GEMV and two equal segments", who);
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
     int bm = 128, bn = 128;
@@ -892,6 +1018,47 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         if (wgs > 0x7fffffffLL)
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
         const size_t lds = (size_t)nvk::kSkinnyWaves * (tm + 1) * t * (bk + 4) * sizeof(float);
+        const dim3 block(64 * nvk::kSkinnyWaves);
+        if (rope || glu || link) { // the 16-row kernel with an epilogue (checked above)
+            using namespace nvk;
+            const long long g = glu ? (n[0] + 7) / 8 : tiles;
+            if (glu)
+                p.n_tiles = (int)g;
+            const void *fused =
+                glu    ? (scale ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, true>
+                                : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, false>)
+                : rope ? (scale ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>
+                                : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>)
+                : resid ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyResid, false>
+                        : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyPlain, true>;
+            static const void *opted_fn[64][8]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
+            bool               seen = false;
+            for (const void *f : opted_fn[device & 63])
+                seen = seen || f == fused;
+            if (!seen) {
+                HIP_TRY(hipFuncSetAttribute(fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                for (const void *&f : opted_fn[device & 63])
+                    if (!f) {
+                        f = fused;
+                        break;
+                    }
+            }
+            const dim3 grid((unsigned)g);
+            if (glu && scale)
+                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, true>), grid, block, lds, st, p);
+            else if (glu)
+                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, false>), grid, block, lds, st, p);
+            else if (rope && scale)
+                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>), grid, block, lds, st, p);
+            else if (rope)
+                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>), grid, block, lds, st, p);
+            else if (resid)
+                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyResid, false>), grid, block, lds, st, p);
+            else
+                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyPlain, true>), grid, block, lds, st, p);
+            HIP_TRY(hipGetLastError());
+            return NVK_OK;
+        }
         const void  *fn  = t == 16 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 64>
                            : tm == 1 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 1, 64>
                            : tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 2, 32>
@@ -902,7 +1069,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             opted[device & 63][slot] = true;
         }
-        const dim3 grid((unsigned)wgs), block(64 * nvk::kSkinnyWaves);
+        const dim3 grid((unsigned)wgs);
         if (t == 16)
             hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 1, 64>), grid, block, lds, st, p);
         else if (tm == 1)
@@ -946,13 +1113,17 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
 
 } // namespace
 
-bool nvk::linked_gemv_ok() { return NVK_GEMV_COLS == 4 && NVK_GEMV_MAX_ROWS >= 1; }
+// partial sums of squares a producer leaves per row: one per 4-column GEMV tile, or per 16-column MFMA tile
+int nvk::linked_ss_n(int rows, int dim) { return rows <= NVK_GEMV_MAX_ROWS ? (dim + 3) / 4 : (dim + 15) / 16; }
+
+bool nvk::linked_gemv_ok() { return NVK_GEMV_COLS == 4 && NVK_GEMV_MAX_ROWS == 2 && NVK_SKINNY16_MAX_ROWS == 16; }
 
 int nvk::linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in_dev, const float *w0_dev,
-                     const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream)
+                     const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream, float *scratch_dev)
 {
-    if (rows < 1 || rows > NVK_GEMV_MAX_ROWS || !out_dev || !in_dev || !w0_dev || (glu && !w1_dev) || in_dim <= 0
-        || out_dim <= 0)
+    if (rows < 1 || rows > kFusedRowsMax || !out_dev || !in_dev || !w0_dev || (glu && !w1_dev) || in_dim <= 0
+        || out_dim <= 0 || (link.ss_out && out_dim % 4 != 0) || (rows > NVK_GEMV_MAX_ROWS && out_dim % 4 != 0)
+        || (rows > NVK_GEMV_MAX_ROWS && link.ss_out && out_dim % 16 != 0))
         return nvk::fail(NVK_ERR_INVALID_ARG, "linked_gemv: bad arguments");
     int rc = check_device(device, "linked_gemv");
     if (rc != NVK_OK)
@@ -961,21 +1132,37 @@ int nvk::linked_gemv(const NormLink &link, bool glu, float *out_dev, const float
     const float *const w[2]   = {w0_dev, w1_dev};
     float *const       out[2] = {out_dev, out_dev};
     const int          n[2]   = {out_dim, out_dim};
+    NormLink l = link;
+    l.ss_out_n = linked_ss_n(rows, out_dim);
+    if (glu && rows > NVK_GEMV_MAX_ROWS) {
+        // the MFMA kernel's SwiGLU tile is 8 + 8 operand rows for 8 outputs: twice the MFMA work per weight byte, measured
+        // slower than the two products in 16-column tiles followed by the element-wise kernel
+        if (!scratch_dev || scratch_dev == out_dev)
+            return nvk::fail(NVK_ERR_INVALID_ARG, "linked_gemv: SwiGLU over more than %d rows needs a scratch buffer",
+                             NVK_GEMV_MAX_ROWS);
+        float *const out2[2] = {out_dev, scratch_dev};
+        rc = launch_linear(in_dev, rows, in_dim, w, out2, n, 2, device, (hipStream_t)stream, "linked_gemv", false, nullptr, &l);
+        if (rc != NVK_OK)
+            return rc;
+        const int64_t count = (int64_t)rows * out_dim;
+        hipLaunchKernelGGL(nvk::nvk_swiglu_kernel, dim3((unsigned)std::min<int64_t>(1024, (count + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, out_dev, scratch_dev, count);
+        HIP_TRY(hipGetLastError());
+        return NVK_OK;
+    }
     return launch_linear(in_dev, rows, in_dim, w, out, n, glu ? 2 : 1, device, (hipStream_t)stream, "linked_gemv", glu,
-                         nullptr, &link);
+                         nullptr, &l);
 }
 
 int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x_dev, const float *wq_dev,
                          const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream,
                          const NormLink *link)
 {
-    if (rows < 1 || rows > kQkvRopeMaxRows || rows > NVK_GEMV_MAX_ROWS || NVK_GEMV_COLS != 4 || dim <= 0 || q_dim <= 0
+    if (!qkv_rope_append_ok(rows, dim, q_dim, t.row_len) || dim <= 0 || q_dim <= 0
         || !q_dev || !x_dev || !wq_dev || !wk_dev || !wv_dev || t.head_dim <= 0 || t.head_dim % 2 != 0
         || q_dim % t.head_dim != 0 || t.row_len % t.head_dim != 0 || !t.k_layer || !t.v_layer || !t.block_tables
         || !t.positions || !t.inv_freq)
         return nvk::fail(NVK_ERR_INVALID_ARG, "qkv_rope_append: bad arguments");
-    if (rows == 2 && (long long)q_dim + 2LL * t.row_len > NVK_GEMV2_MAX_COLS)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "qkv_rope_append: two rows of %d columns are not a GEMV", q_dim + 2 * t.row_len);
     int rc = check_device(device, "qkv_rope_append");
     if (rc != NVK_OK)
         return rc;
@@ -989,8 +1176,10 @@ int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x
 // can rows x (q_dim + 2 kv_dim) go through qkv_rope_append?
 bool nvk::qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim)
 {
-    return NVK_GEMV_COLS == 4 && rows >= 1 && rows <= kQkvRopeMaxRows && rows <= NVK_GEMV_MAX_ROWS && dim % 4 == 0
-           && (rows < 2 || (long long)q_dim + 2LL * kv_dim <= NVK_GEMV2_MAX_COLS);
+    if (NVK_GEMV_COLS != 4 || NVK_GEMV_MAX_ROWS < 2 || NVK_SKINNY16_MAX_ROWS != 16 || rows < 1 || rows > kFusedRowsMax
+        || dim % 4 != 0 || q_dim % 4 != 0 || kv_dim % 4 != 0)
+        return false;
+    return true; // one or two rows: the GEMV (a pair inside a 4-column tile); up to 16: the 16 x 16 MFMA kernel
 }
 
 extern "C" {

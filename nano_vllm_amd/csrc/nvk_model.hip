@@ -470,19 +470,19 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
         return code;
     };
     // everything between the batch's bookkeeping and the host's wait: tokens in, embedding .. sampler, next tokens out
-    // One or two decoding rows (the reference's own case is one): 6 launches per layer instead of 8.  The residual adds sit in the
+    // Up to 16 decoding rows (the reference's own case is one): 6 launches per layer instead of 10.  The residual adds sit in the
     // epilogues of the wo and w_down GEMVs, which also leave x * gain and the partial sums of squares for the next
     // norm; the GEMV that consumes them multiplies its product by 1 / rms (nvk::NormLink).  xn holds x * gain, xb the
     // partial sums.  Layer 0's first norm has no producer and stays a kernel.
     const bool linked = m->use_linked && R == n && nvk::linked_gemv_ok() && m->rope_theta > 0.f && m->head_dim % 2 == 0
-                        && Hd % 4 == 0 && QD % 4 == 0
+                        && D % 4 == 0 && Hd % 4 == 0 && QD % 4 == 0 && (R <= 2 || (V % 4 == 0 && m->head_dim % 4 == 0 && D % 16 == 0))
                         && nvk::qkv_rope_append_ok(R, D, QD, m->n_kv_heads * m->head_dim);
     auto enqueue_linked = [&]() -> int {
         hipError_t e1 = hipMemcpyAsync(m->tokens_dev, h_tok, (size_t)R * sizeof(int), hipMemcpyHostToDevice, st);
         if (e1 != hipSuccess)
             return nvk::fail(NVK_ERR_HIP, "nvk_model_step_chunks: staging the tokens failed: %s", hipGetErrorString(e1));
         hipLaunchKernelGGL(nvk_embed_kernel, dim3((unsigned)R), dim3(64), 0, st, m->x, m->tok_emb, m->tokens_dev, D, V);
-        const int tiles_d = (D + 3) / 4;
+        const int tiles_d = nvk::linked_ss_n(R, D);
         auto      produce = [&](const float *gain) { // x += in . w^T; xn = x * gain; xb = partial sums of x^2
             nvk::NormLink l;
             l.gain_out = gain, l.xg_out = m->xn, l.ss_out = m->xb, l.eps = m->rms_eps;
@@ -502,7 +502,7 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
             if (r2 == NVK_OK) // :224, :227-228 and the operands of :231
                 r2 = nvk::linked_gemv(produce(w.rms_ffn), false, m->x, m->att, w.wo, nullptr, R, QD, D, m->device, (void *)st);
             if (r2 == NVK_OK) // :231-234
-                r2 = nvk::linked_gemv(consume, true, m->hb, m->xn, w.w_gate, w.w_up, R, D, Hd, m->device, (void *)st);
+                r2 = nvk::linked_gemv(consume, true, m->hb, m->xn, w.w_gate, w.w_up, R, D, Hd, m->device, (void *)st, m->hb2);
             if (r2 == NVK_OK) // :235, :238-239 and the operands of the next norm (the next layer's :161, or :243)
                 r2 = nvk::linked_gemv(produce(l + 1 < m->n_layers ? m->layers[(size_t)l + 1].rms_att : m->rms_final), false,
                                       m->x, m->hb, w.w_down, nullptr, R, Hd, D, m->device, (void *)st);

@@ -215,22 +215,22 @@ def test_graph_replay_gives_the_bits_of_direct_launches(spec, n_requests, checkp
     assert np.array_equal(runs[True], runs[False])
 
 
-@pytest.mark.parametrize("n_req", [1, 2])
+@pytest.mark.parametrize("n_req", [1, 2, 3, 7])
 @pytest.mark.parametrize("spec", TINY_MODELS, ids=[s["name"] for s in TINY_MODELS])
 def test_norms_carried_between_the_gemvs(spec, n_req, checkpoints):
-    """A step of one or two decoding rows carries its RMSNorms between the GEMVs (nvk_model_use_linked_norms: the
+    """A step of up to 16 decoding rows carries its RMSNorms between the GEMVs (nvk_model_use_linked_norms: the
     producer leaves x * gain and partial sums of squares, the consumer multiplies its product by 1 / rms).  Against
     the norms as kernels the logits agree 10x tighter than the bar the whole model is held to against the reference
     (teacher forced, step by step), with and without the graph; the graph does not change a bit."""
     import nano_vllm_amd as nv
 
     rng = np.random.default_rng(12)
-    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=k).tolist() for k in (6, 3)][:n_req]
-    ids = [5, 9][:n_req]
+    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=k).tolist() for k in (6, 3, 1, 4, 2, 5, 3)][:n_req]
+    ids = [5, 9, 2, 11, 3, 8, 6][:n_req]
     steps = min(30, spec["max_seq_len"] - 10)
     runs, fed = {}, None
     for linked, graphs in ((False, False), (True, False), (True, True)):
-        with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"], max_seqs=2) as m:
+        with nv.LlamaModel(checkpoints[spec["name"]], spec["block_size"], spec["num_blocks"], max_seqs=max(2, n_req)) as m:
             m.use_linked_norms(linked)
             m.use_graphs(graphs)
             for r in ids:
