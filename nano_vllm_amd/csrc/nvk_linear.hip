@@ -67,6 +67,9 @@
 #ifndef NVK_SKINNY16_MAX_ROWS
 #define NVK_SKINNY16_MAX_ROWS 16 // up to here the weight-streaming kernel uses 16 x 16 MFMA tiles (0: always 32 x 32)
 #endif
+#ifndef NVK_SKINNY16_WIDE
+#define NVK_SKINNY16_WIDE 1 // 17-64 rows over few columns: 16 x 16 tiles, one workgroup per row tile (0: 32 x 32 tiles)
+#endif
 #ifndef NVK_SKINNY_MAX_ROWS
 #define NVK_SKINNY_MAX_ROWS 96 // up to here the weight-streaming MFMA kernel (32-row tiles), above it the tiled one
 #endif
@@ -939,6 +942,14 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     }
     if (glu && !(((gemv && NVK_GEMV_COLS == 4) || !gemv) && nseg == 2 && n[0] == n[1] && n[0] > 0))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the GLU form needs the GEMV and two equal segments", who);
+    static int cu_count[64]; // per device, asked once
+    if (cu_count[device & 63] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
+            n = 256;
+        cu_count[device & 63] = n;
+    }
+    const int cus = cu_count[device & 63];
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
     int bm = 128, bn = 128;
     if (!gemv && !skinny) {
@@ -946,22 +957,23 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         for (int s = 0; s < nseg; s++)
             t128 += (n[s] + 127) / 128;
         t128 *= (batch + 127) / 128;
-        static int cu_count[64]; // per device, asked once
-        if (cu_count[device & 63] == 0) {
-            int n = 0;
-            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
-                n = 256;
-            cu_count[device & 63] = n;
-        }
-        const int cus = cu_count[device & 63];
         // measured (profiles/r01_qkv_projection.log): two 128 x 128 workgroups fit a CU, and a launch that is not
         // at least three full rounds of them loses more to the ragged last round than 64 x 64 tiles lose to their
         // four times higher LDS and L2 traffic per flop
         if (NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
             bm = bn = 64;
     }
-    else
-        bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (batch <= NVK_SKINNY16_MAX_ROWS ? 16 : 32);
+    else {
+        // 16 x 16 tiles: always up to 16 rows; with more rows (several row tiles per column tile, the weights' second
+        // reading an L2 hit) while 32-column tiles would leave CUs idle -- measured (profiles/r01_qkv_projection.log):
+        // 2048 columns x 32 rows 14.6 -> 7.5 us, 5632 -> 2048 at 32 / 64 rows 36.5 -> 16.5 / 37.6 -> 31.2 us
+        long long t32 = 0;
+        for (int s = 0; s < nseg; s++)
+            t32 += (n[s] + 31) / 32;
+        const bool t16 = batch <= NVK_SKINNY16_MAX_ROWS || (NVK_SKINNY16_WIDE && batch <= 32 && t32 < cus)
+                         || (NVK_SKINNY16_WIDE && batch <= 64 && t32 <= cus / 4);
+        bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (t16 ? 16 : 32);
+    }
     long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
