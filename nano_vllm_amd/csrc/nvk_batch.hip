@@ -597,7 +597,7 @@ bool decode_rows_fuse(const nvk_batch *b, int rows, int dim, float rope_theta)
 {
     const bool all_decode = !b->chunked || b->n_decode == (int)b->step_ids.size();
     return all_decode && rope_theta > 0.f && b->head_dim % 2 == 0 && (rows <= 2 || b->head_dim % 4 == 0)
-           && nvk::qkv_rope_append_ok(rows, dim, b->n_heads * b->head_dim, b->row_len);
+           && nvk::qkv_rope_append_ok(rows, dim, b->n_heads * b->head_dim, b->row_len, b->device);
 }
 
 // model.hpp:164-175, 190-207, 221 for such a step: q | k | v GEMV with the rotation and the append in its epilogue, then

@@ -51,7 +51,7 @@ int pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const i
                             const int *positions_dev, RopeAppendTarget *out);
 // q_dev [rows, q_dim] = rope(wq . x); rope(wk . x) and wv . x go straight to the cache slots of the rows' positions
 // (model.hpp:164-175, 190-207 in one launch; the arithmetic of the separate kernels, so the same bits).
-// rows <= kQkvRopeMaxRows.
+// qkv_rope_append_ok(rows, ...) must hold (up to 16 rows always, up to 32 over few columns).
 int qkv_rope_append(const RopeAppendTarget &target, float *q_dev, const float *x_dev, const float *wq_dev,
                     const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream,
                     const NormLink *link = nullptr);
@@ -59,6 +59,6 @@ int qkv_rope_append(const RopeAppendTarget &target, float *q_dev, const float *x
 int batch_layer_hidden_linked(nvk_batch *b, int layer, const float *xg_dev, int dim, const NormLink &link,
                               const float *wq_dev, const float *wk_dev, const float *wv_dev, float *out_dev,
                               float rope_theta, void *stream);
-bool qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim);
+bool qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim, int device);
 
 } // namespace nvk

@@ -898,6 +898,31 @@ int check_device(int device, const char *who)
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // One launch for up to three (weight, out, n) segments sharing the activations `in` [batch, in_dim].
+int cu_count_of(int device)
+{
+    static int cu_count[64]; // per device, asked once
+    if (cu_count[device & 63] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
+            n = 256;
+        cu_count[device & 63] = n;
+    }
+    return cu_count[device & 63];
+}
+
+// 16 x 16 tiles in the weight-streaming MFMA kernel: always up to 16 rows; with more rows (several row tiles per
+// column tile, the weights' further readings L2 hits) while 32-column tiles would leave CUs idle -- measured
+// (profiles/r01_qkv_projection.log): 2048 columns x 32 rows 14.6 -> 7.5 us, 5632 -> 2048 at 32 / 64 rows
+// 36.5 -> 16.5 / 37.6 -> 31.2 us
+bool tile16(int batch, const int *n, int nseg, int cus)
+{
+    long long t32 = 0;
+    for (int s = 0; s < nseg; s++)
+        t32 += (n[s] + 31) / 32;
+    return batch <= NVK_SKINNY16_MAX_ROWS || (NVK_SKINNY16_WIDE && batch <= 32 && t32 < cus)
+           || (NVK_SKINNY16_WIDE && batch <= 64 && t32 <= cus / 4);
+}
+
 int launch_linear(const float *in, int batch, int in_dim, const float *const *w, float *const *out, const int *n,
                   int nseg, int device, hipStream_t st, const char *who, bool glu = false,
                   const nvk::RopeAppendTarget *rope = nullptr, const nvk::NormLink *link = nullptr)
@@ -919,7 +944,12 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     // (a norm link exists only in the GEMV: two linked rows stay there at any width)
     const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS || link);
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
-    if ((rope || glu || link) && !gemv && !(batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16))
+    const int  cus = cu_count_of(device);
+    const bool t16 = tile16(batch, n, nseg, cus);
+    // fused epilogues beyond the GEMV: the 16 x 16 tile kernel -- the norm link and SwiGLU up to 16 rows, RoPE + append
+    // wherever that kernel is chosen up to 32 rows
+    if (!gemv && (((glu || link) && !(batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16))
+                  || (rope && !(t16 && batch <= 32))))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: no fused epilogue for %d rows", who, batch);
     if ((rope || glu || link) && !gemv) {
         for (int s = 0; s < nseg; s++)
@@ -942,14 +972,6 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     }
     if (glu && !(((gemv && NVK_GEMV_COLS == 4) || !gemv) && nseg == 2 && n[0] == n[1] && n[0] > 0))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the GLU form needs the GEMV and two equal segments", who);
-    static int cu_count[64]; // per device, asked once
-    if (cu_count[device & 63] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
-            n = 256;
-        cu_count[device & 63] = n;
-    }
-    const int cus = cu_count[device & 63];
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
     int bm = 128, bn = 128;
     if (!gemv && !skinny) {
@@ -963,17 +985,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         if (NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
             bm = bn = 64;
     }
-    else {
-        // 16 x 16 tiles: always up to 16 rows; with more rows (several row tiles per column tile, the weights' second
-        // reading an L2 hit) while 32-column tiles would leave CUs idle -- measured (profiles/r01_qkv_projection.log):
-        // 2048 columns x 32 rows 14.6 -> 7.5 us, 5632 -> 2048 at 32 / 64 rows 36.5 -> 16.5 / 37.6 -> 31.2 us
-        long long t32 = 0;
-        for (int s = 0; s < nseg; s++)
-            t32 += (n[s] + 31) / 32;
-        const bool t16 = batch <= NVK_SKINNY16_MAX_ROWS || (NVK_SKINNY16_WIDE && batch <= 32 && t32 < cus)
-                         || (NVK_SKINNY16_WIDE && batch <= 64 && t32 <= cus / 4);
+    else
         bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (t16 ? 16 : 32);
-    }
     long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
@@ -1033,7 +1046,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         const dim3 block(64 * nvk::kSkinnyWaves);
         if (rope || glu || link) { // the 16-row kernel with an epilogue (checked above)
             using namespace nvk;
-            const long long g = glu ? (n[0] + 7) / 8 : tiles;
+            const long long g = glu ? (n[0] + 7) / 8 : wgs; // (several row tiles only with the RoPE epilogue)
             if (glu)
                 p.n_tiles = (int)g;
             const void *fused =
@@ -1170,7 +1183,7 @@ int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x
                          const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream,
                          const NormLink *link)
 {
-    if (!qkv_rope_append_ok(rows, dim, q_dim, t.row_len) || dim <= 0 || q_dim <= 0
+    if (!qkv_rope_append_ok(rows, dim, q_dim, t.row_len, device) || dim <= 0 || q_dim <= 0
         || !q_dev || !x_dev || !wq_dev || !wk_dev || !wv_dev || t.head_dim <= 0 || t.head_dim % 2 != 0
         || q_dim % t.head_dim != 0 || t.row_len % t.head_dim != 0 || !t.k_layer || !t.v_layer || !t.block_tables
         || !t.positions || !t.inv_freq)
@@ -1186,12 +1199,15 @@ int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x
 }
 
 // can rows x (q_dim + 2 kv_dim) go through qkv_rope_append?
-bool nvk::qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim)
+bool nvk::qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim, int device)
 {
-    if (NVK_GEMV_COLS != 4 || NVK_GEMV_MAX_ROWS < 2 || NVK_SKINNY16_MAX_ROWS != 16 || rows < 1 || rows > kFusedRowsMax
-        || dim % 4 != 0 || q_dim % 4 != 0 || kv_dim % 4 != 0)
+    if (NVK_GEMV_COLS != 4 || NVK_GEMV_MAX_ROWS < 2 || NVK_SKINNY16_MAX_ROWS != 16 || rows < 1 || rows > 32 || dim % 4 != 0
+        || q_dim % 4 != 0 || kv_dim % 4 != 0)
         return false;
-    return true; // one or two rows: the GEMV (a pair inside a 4-column tile); up to 16: the 16 x 16 MFMA kernel
+    // one or two rows: the GEMV (a pair inside a 4-column tile); up to 16: the 16 x 16 MFMA kernel; up to 32 where that
+    // kernel is the one chosen
+    const int n[3] = {q_dim, kv_dim, kv_dim};
+    return rows <= kFusedRowsMax || tile16(rows, n, 3, cu_count_of(device));
 }
 
 extern "C" {

@@ -476,7 +476,7 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
     // partial sums.  Layer 0's first norm has no producer and stays a kernel.
     const bool linked = m->use_linked && R == n && nvk::linked_gemv_ok() && m->rope_theta > 0.f && m->head_dim % 2 == 0
                         && D % 4 == 0 && Hd % 4 == 0 && QD % 4 == 0 && (R <= 2 || (V % 4 == 0 && m->head_dim % 4 == 0 && D % 16 == 0))
-                        && nvk::qkv_rope_append_ok(R, D, QD, m->n_kv_heads * m->head_dim);
+                        && R <= nvk::kFusedRowsMax && nvk::qkv_rope_append_ok(R, D, QD, m->n_kv_heads * m->head_dim, m->device);
     auto enqueue_linked = [&]() -> int {
         hipError_t e1 = hipMemcpyAsync(m->tokens_dev, h_tok, (size_t)R * sizeof(int), hipMemcpyHostToDevice, st);
         if (e1 != hipSuccess)
