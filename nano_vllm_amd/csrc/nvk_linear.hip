@@ -372,16 +372,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // TM > 1 (T = 32 only): one wave multiplies TM row tiles by the same weight tile, so up to 32 * TM rows still stream
 // the weights once; BK is then 32 so that the waves' private LDS regions fit.
 // EPI / SCALE (T = 16, TM = 1: up to 16 rows): the epilogues of nvk_gemv_kernel for decode steps of a few requests --
-// kSkinnyResid and SCALE are the two ends of a NormLink, kSkinnyGlu is SwiGLU (the tile is 8 gate rows + the same 8
-// rows of up, 8 output columns), kSkinnyRope is RoPE + KV append.  See nvk_gemv_kernel and nvk_internal.h.
-enum { kSkinnyPlain = 0, kSkinnyResid = 1, kSkinnyGlu = 2, kSkinnyRope = 3 };
+// kSkinnyResid and SCALE are the two ends of a NormLink, kSkinnyRope is RoPE + KV append (see nvk_gemv_kernel and
+// nvk_internal.h).  SwiGLU has no form here: an 8 + 8 row tile doubles the MFMA work per weight byte and measured slower
+// than the two products followed by the element-wise kernel.
+enum { kSkinnyPlain = 0, kSkinnyResid = 1, kSkinnyRope = 2 };
 
 template <int T, int TM, int BK, int EPI = kSkinnyPlain, bool SCALE = false>
 __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
 {
     static_assert((EPI == kSkinnyPlain && !SCALE) || (T == 16 && TM == 1 && BK == 64), "epilogues: the 16-row kernel");
     __shared__ float s_ssq[16]; // SCALE: every row's sum of squares
-    constexpr bool GLU = EPI == kSkinnyGlu;
     constexpr int LDS = BK + 4;             // row stride in LDS (floats)
     constexpr int LPR = BK / 4, RPI = 64 / LPR; // lanes per tile row, rows per load instruction
     constexpr int RW = T / RPI, RX = TM * T / RPI; // float4 per lane per step: weights, activations
@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     const int m0   = rem / 8 * (TM * T);
     if (nt >= p.n_tiles)
         return;
-    const LinearSeg sg = GLU ? p.seg[0] : segment_of(p, nt);
-    const int       n0 = GLU ? nt * 8 : (nt - sg.tile0) * T;
+    const LinearSeg sg = segment_of(p, nt);
+    const int       n0 = (nt - sg.tile0) * T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & (T - 1), part = lane / T; // MFMA operand row / column, and which k lanes of the instruction
     const int lr = lane / LPR, lc = (lane % LPR) * 4;
@@ -405,16 +405,14 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     for (int i = 0; i < RX; i++)
         aoff[i] = min(m0 + lr + RPI * i, p.m - 1) * p.lda + lc;
 #pragma unroll
-    for (int i = 0; i < RW; i++) // GLU: operand rows 0-7 are gate rows n0 .., rows 8-15 the same rows of up
-        woff[i] = min(n0 + (GLU ? (lr + RPI * i) & 7 : lr + RPI * i), sg.n - 1) * p.k + lc;
+    for (int i = 0; i < RW; i++)
+        woff[i] = min(n0 + lr + RPI * i, sg.n - 1) * p.k + lc;
     float4 rx[RX], rw0[RW], rw1[RW];
     auto   fetch_w = [&](float4(&r)[RW], int k0) {
         const bool inside = k0 + lc < p.k;
 #pragma unroll
-        for (int i = 0; i < RW; i++) {
-            const float *base = GLU && RPI * i >= 8 ? p.seg[1].w : sg.w; // (RPI = 4: uniform in i)
-            r[i] = inside ? load_stream(base + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < RW; i++)
+            r[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto fetch_x = [&](int k0) {
         const bool inside = k0 + lc < p.k;
@@ -569,19 +567,6 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
                 v += __shfl_xor(v, 2);
                 if (cg == 0 && row < p.m && col < sg.n)
                     p.link.ss_out[row * p.link.ss_out_n + col / 16] = v;
-            }
-            else if (EPI == kSkinnyGlu) {
-                if (cg < 8) { // gate in operand columns 0-7, up in 8-15 of the same rows
-                    float4 up = total(l4 + 8);
-                    up.x *= rms, up.y *= rms, up.z *= rms, up.w *= rms;
-                    if (whole) {
-#pragma clang fp contract(off) // silu(g) * u as the separate kernel (activation.hpp:34-40)
-                        float4 o;
-                        o.x = sum.x / (1.0f + expf(-sum.x)) * up.x, o.y = sum.y / (1.0f + expf(-sum.y)) * up.y;
-                        o.z = sum.z / (1.0f + expf(-sum.z)) * up.z, o.w = sum.w / (1.0f + expf(-sum.w)) * up.w;
-                        *reinterpret_cast<float4 *>(sg.out + (int64_t)row * sg.ldo + col) = o;
-                    }
-                }
             }
             else if (whole) { // kSkinnyRope: nvk_rope_append_kernel's arithmetic on the row's q / k / v columns
                 const RopeAppendTarget &t  = p.rope;
@@ -946,12 +931,12 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
     const int  cus = cu_count_of(device);
     const bool t16 = tile16(batch, n, nseg, cus);
-    // fused epilogues beyond the GEMV: the 16 x 16 tile kernel -- the norm link and SwiGLU up to 16 rows, RoPE + append
-    // wherever that kernel is chosen up to 32 rows
-    if (!gemv && (((glu || link) && !(batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16))
+    // fused epilogues beyond the GEMV: the 16 x 16 tile kernel -- the norm link up to 16 rows, RoPE + append wherever
+    // that kernel is chosen up to 32 rows; SwiGLU only in the GEMV
+    if (!gemv && (glu || (link && !(batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16))
                   || (rope && !(t16 && batch <= 32))))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: no fused epilogue for %d rows", who, batch);
-    if ((rope || glu || link) && !gemv) {
+    if ((rope || link) && !gemv) {
         for (int s = 0; s < nseg; s++)
             if (n[s] % 4 != 0)
                 return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: fused epilogues need out_dim %% 4 == 0", who);
@@ -970,7 +955,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: a norm link needs the GEMV (scale in, or residual out)", who);
         p.link = *link;
     }
-    if (glu && !(((gemv && NVK_GEMV_COLS == 4) || !gemv) && nseg == 2 && n[0] == n[1] && n[0] > 0))
+    if (glu && !(gemv && NVK_GEMV_COLS == 4 && nseg == 2 && n[0] == n[1] && n[0] > 0))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: the GLU form needs the GEMV and two equal segments", who);
     // tiled kernel: 128 x 128 tiles when they fill the chip about twice over, else 64 x 64 (four times the workgroups)
     int bm = 128, bn = 128;
@@ -1044,19 +1029,14 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
         const size_t lds = (size_t)nvk::kSkinnyWaves * (tm + 1) * t * (bk + 4) * sizeof(float);
         const dim3 block(64 * nvk::kSkinnyWaves);
-        if (rope || glu || link) { // the 16-row kernel with an epilogue (checked above)
+        if (rope || link) { // the 16 x 16 tile kernel with an epilogue (checked above)
             using namespace nvk;
-            const long long g = glu ? (n[0] + 7) / 8 : wgs; // (several row tiles only with the RoPE epilogue)
-            if (glu)
-                p.n_tiles = (int)g;
             const void *fused =
-                glu    ? (scale ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, true>
-                                : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, false>)
-                : rope ? (scale ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>
-                                : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>)
+                rope    ? (scale ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>
+                                 : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>)
                 : resid ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyResid, false>
                         : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyPlain, true>;
-            static const void *opted_fn[64][8]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
+            static const void *opted_fn[64][4]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
             bool               seen = false;
             for (const void *f : opted_fn[device & 63])
                 seen = seen || f == fused;
@@ -1068,12 +1048,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
                         break;
                     }
             }
-            const dim3 grid((unsigned)g);
-            if (glu && scale)
-                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, true>), grid, block, lds, st, p);
-            else if (glu)
-                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyGlu, false>), grid, block, lds, st, p);
-            else if (rope && scale)
+            const dim3 grid((unsigned)wgs); // (several row tiles only with the RoPE epilogue)
+            if (rope && scale)
                 hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>), grid, block, lds, st, p);
             else if (rope)
                 hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>), grid, block, lds, st, p);
