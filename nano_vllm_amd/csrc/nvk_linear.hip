@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "nvk_device_scope.h"
 #include "nvk_addr.hip.h"
@@ -883,9 +884,12 @@ int check_device(int device, const char *who)
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // One launch for up to three (weight, out, n) segments sharing the activations `in` [batch, in_dim].
+std::mutex g_first_use; // the per-device caches below are filled on first use, possibly from several threads
+
 int cu_count_of(int device)
 {
-    static int cu_count[64]; // per device, asked once
+    static int                  cu_count[64]; // per device, asked once
+    std::lock_guard<std::mutex> lock(g_first_use);
     if (cu_count[device & 63] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0)
@@ -893,6 +897,25 @@ int cu_count_of(int device)
         cu_count[device & 63] = n;
     }
     return cu_count[device & 63];
+}
+
+// more than 64 KiB of dynamic LDS needs the attribute, once per device and kernel
+int opt_in_lds(const void *kernel, size_t lds_bytes, int device)
+{
+    static const void          *done[64][16];
+    std::lock_guard<std::mutex> lock(g_first_use);
+    const void                **row = done[device & 63];
+    for (int i = 0; i < 16; i++) {
+        if (row[i] == kernel)
+            return NVK_OK;
+        if (!row[i]) {
+            HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            row[i] = kernel;
+            return NVK_OK;
+        }
+    }
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); // table full: every time
+    return NVK_OK;
 }
 
 // 16 x 16 tiles in the weight-streaming MFMA kernel: always up to 16 rows; with more rows (several row tiles per
@@ -1036,18 +1059,9 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
                                  : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>)
                 : resid ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyResid, false>
                         : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyPlain, true>;
-            static const void *opted_fn[64][4]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
-            bool               seen = false;
-            for (const void *f : opted_fn[device & 63])
-                seen = seen || f == fused;
-            if (!seen) {
-                HIP_TRY(hipFuncSetAttribute(fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                for (const void *&f : opted_fn[device & 63])
-                    if (!f) {
-                        f = fused;
-                        break;
-                    }
-            }
+            int rc_lds = opt_in_lds(fused, lds, device);
+            if (rc_lds != NVK_OK)
+                return rc_lds;
             const dim3 grid((unsigned)wgs); // (several row tiles only with the RoPE epilogue)
             if (rope && scale)
                 hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>), grid, block, lds, st, p);
@@ -1064,12 +1078,9 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
                            : tm == 1 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 1, 64>
                            : tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 2, 32>
                                      : (const void *)nvk::nvk_gemm_skinny_kernel<32, 3, 32>;
-        const int    slot = t == 16 ? 0 : tm;
-        static bool  opted[64][4]; // > 64 KiB of dynamic LDS needs the attribute, once per device and kernel
-        if (!opted[device & 63][slot]) {
-            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            opted[device & 63][slot] = true;
-        }
+        int rc_lds = opt_in_lds(fn, lds, device);
+        if (rc_lds != NVK_OK)
+            return rc_lds;
         const dim3 grid((unsigned)wgs);
         if (t == 16)
             hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 1, 64>), grid, block, lds, st, p);
@@ -1088,21 +1099,15 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         const int    bk  = bm == 128 ? 32 : (batch <= 256 ? 64 : 32); // 64 x 64: fewer barriers while waves are few
         const size_t lds = (size_t)2 * (bm + bn) * (bk + 4) * sizeof(float);
         if (bm == 128) {
-            static bool opted[64];
-            if (!opted[device & 63]) {
-                HIP_TRY(hipFuncSetAttribute((const void *)nvk::nvk_gemm_nt_kernel<128, 128, 32>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                opted[device & 63] = true;
-            }
+            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<128, 128, 32>, lds, device);
+            if (rc_lds != NVK_OK)
+                return rc_lds;
             hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<128, 128, 32>), dim3((unsigned)wgs), dim3(256), lds, st, p);
         }
         else if (bk == 64) {
-            static bool opted[64];
-            if (!opted[device & 63]) {
-                HIP_TRY(hipFuncSetAttribute((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                opted[device & 63] = true;
-            }
+            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64>, lds, device);
+            if (rc_lds != NVK_OK)
+                return rc_lds;
             hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<64, 64, 64>), dim3((unsigned)wgs), dim3(256), lds, st, p);
         }
         else
