@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace nvk {
 
 // Makes `device` current and restores the caller's device after; when it already is current (the usual case: one
@@ -32,13 +34,14 @@ struct DeviceScope
 // hipGetDeviceCount, asked once per process (0 when no device is visible or the runtime fails)
 inline int device_count_cached()
 {
-    static int cached = 0;
-    if (cached > 0)
-        return cached;
+    static std::atomic<int> cached{0};
+    const int               seen = cached.load(std::memory_order_relaxed);
+    if (seen > 0)
+        return seen;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return 0; // keep asking while there is none
-    cached = n;
+    cached.store(n, std::memory_order_relaxed);
     return n;
 }
 
