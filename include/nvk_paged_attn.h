@@ -350,8 +350,8 @@ int nvk_batch_layer(nvk_batch *batch, int layer, float *q_dev, const float *k_ro
 /* The same layer from the hidden state (include/core/model.hpp:161-221 in one call): x [rows, dim] ->
  * rms_norm (rms_weight NULL: x is already normalised) -> q / k / v projections (nvk_qkv_project_device) ->
  * RoPE + append + attention as nvk_batch_layer.  q / k / v live in scratch rows the batch keeps (grown, with a
- * device synchronisation, the first time a step needs more).  A step whose rows all decode, up to 16 of them (32
- * over few columns), runs the projections, the rotation and the append as ONE launch: the epilogue of the projection
+ * device synchronisation, the first time a step needs more).  A step whose rows all decode, up to 16 of them (up
+ * to 96 for most shapes), runs the projections, the rotation and the append as ONE launch: the epilogue of the projection
  * kernel rotates q and k in their pairs and writes k and v straight to the rows' cache slots -- the arithmetic of the
  * separate kernels, so the same bits in `out` and in the pool. */
 int nvk_batch_layer_hidden(nvk_batch *batch, int layer, const float *x_dev, int dim, const float *rms_weight_dev,

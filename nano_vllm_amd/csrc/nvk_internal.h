@@ -51,7 +51,7 @@ int pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const i
                             const int *positions_dev, RopeAppendTarget *out);
 // q_dev [rows, q_dim] = rope(wq . x); rope(wk . x) and wv . x go straight to the cache slots of the rows' positions
 // (model.hpp:164-175, 190-207 in one launch; the arithmetic of the separate kernels, so the same bits).
-// qkv_rope_append_ok(rows, ...) must hold (up to 16 rows always, up to 32 over few columns).
+// qkv_rope_append_ok(rows, ...) must hold (up to 16 rows always; up to 96 where every row tile has its own workgroup).
 int qkv_rope_append(const RopeAppendTarget &target, float *q_dev, const float *x_dev, const float *wq_dev,
                     const float *wk_dev, const float *wv_dev, int rows, int dim, int q_dim, int device, void *stream,
                     const NormLink *link = nullptr);

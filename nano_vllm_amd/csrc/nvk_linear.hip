@@ -372,6 +372,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32 -- half the MFMA cycles spent on padding rows, twice the workgroups, half the LDS.
 // TM > 1 (T = 32 only): one wave multiplies TM row tiles by the same weight tile, so up to 32 * TM rows still stream
 // the weights once; BK is then 32 so that the waves' private LDS regions fit.
+// Four consecutive columns (col % 4 == 0) of row `row` of the q | k | v product, segment si = 0 / 1 / 2: what
+// nvk_rope_append_kernel does with them -- q and k rotated in their pairs by the row's position (positional.hpp:13-39),
+// q to `q_out`, k and v to the slot of token `pos` in the row's sequence (model.hpp:190-207).
+__device__ __forceinline__ void rope_append_store(const RopeAppendTarget &t, int si, int row, int col, float4 sum, float *q_out)
+{
+    const int pos = t.positions[row];
+    if (pos < 0) // (the row is skipped, as nvk_rope_append_kernel does)
+        return;
+    float4 o = sum;
+    if (si < 2) {
+        const int   pr = (col % t.head_dim) >> 1, pr1 = ((col + 2) % t.head_dim) >> 1;
+        const float a0 = (float)pos * t.inv_freq[pr], a1 = (float)pos * t.inv_freq[pr1];
+        double      s0, c0, s1, c1;
+        sincos((double)a0, &s0, &c0);
+        sincos((double)a1, &s1, &c1);
+        const float2 p0 = rope_rotate(make_float2(sum.x, sum.y), make_float2((float)c0, (float)s0));
+        const float2 p1 = rope_rotate(make_float2(sum.z, sum.w), make_float2((float)c1, (float)s1));
+        o               = make_float4(p0.x, p0.y, p1.x, p1.y);
+    }
+    if (si == 0) {
+        *reinterpret_cast<float4 *>(q_out) = o;
+        return;
+    }
+    const int     blk = token_block(pos, t.bs_magic);
+    const int     off = token_offset(pos, blk, t.block_size);
+    const int     pb  = clamp_block(t.block_tables[(int64_t)row * t.max_blocks + blk], t.num_blocks);
+    const int64_t at  = ((int64_t)pb * t.block_size + off) * t.row_len + col;
+    *reinterpret_cast<float4 *>((si == 1 ? t.k_layer : t.v_layer) + at) = o;
+}
+
 // EPI / SCALE (T = 16, TM = 1: up to 16 rows): the epilogues of nvk_gemv_kernel for decode steps of a few requests --
 // kSkinnyResid and SCALE are the two ends of a NormLink, kSkinnyRope is RoPE + KV append (see nvk_gemv_kernel and
 // nvk_internal.h).  SwiGLU has no form here: an 8 + 8 row tile doubles the MFMA work per weight byte and measured slower
@@ -381,7 +411,9 @@ enum { kSkinnyPlain = 0, kSkinnyResid = 1, kSkinnyRope = 2 };
 template <int T, int TM, int BK, int EPI = kSkinnyPlain, bool SCALE = false>
 __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
 {
-    static_assert((EPI == kSkinnyPlain && !SCALE) || (T == 16 && TM == 1 && BK == 64), "epilogues: the 16-row kernel");
+    static_assert((EPI == kSkinnyPlain && !SCALE) || (T == 16 && TM == 1 && BK == 64)
+                      || (EPI == kSkinnyRope && !SCALE && T == 32 && TM == 1 && BK == 64),
+                  "epilogues: the 16 x 16 tile kernel; RoPE + append also on 32 x 32 tiles");
     __shared__ float s_ssq[16]; // SCALE: every row's sum of squares
     constexpr int LDS = BK + 4;             // row stride in LDS (floats)
     constexpr int LPR = BK / 4, RPI = 64 / LPR; // lanes per tile row, rows per load instruction
@@ -529,7 +561,7 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
         for (int r = 0; r < NACC; r++)
             sa[(t * NACC + r) * 64 + lane] = T == 32 ? acc32[t][r] : acc16[r & 3]; // own region: operand reads are behind us
     __syncthreads();
-    if (EPI != kSkinnyPlain || SCALE) { // T = 16, TM = 1: thread (r, l4) owns row 4 * (l4 / 16) + r, columns (l4 % 16) .. + 3
+    if (T == 16 && (EPI != kSkinnyPlain || SCALE)) { // T = 16, TM = 1: thread (r, l4) owns row 4 * (l4 / 16) + r, columns (l4 % 16) .. + 3
         if (tid < 64) {
             const int r = tid >> 4, l4 = (tid & 15) * 4, cg = l4 & 15;
             const int row = m0 + 4 * (l4 / T) + r;
@@ -569,32 +601,9 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
                 if (cg == 0 && row < p.m && col < sg.n)
                     p.link.ss_out[row * p.link.ss_out_n + col / 16] = v;
             }
-            else if (whole) { // kSkinnyRope: nvk_rope_append_kernel's arithmetic on the row's q / k / v columns
-                const RopeAppendTarget &t  = p.rope;
-                const int               si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
-                const int               pos = t.positions[row];
-                if (pos >= 0) {
-                    float4 o = sum;
-                    if (si < 2) {
-                        const int   pr = (col % t.head_dim) >> 1, pr1 = ((col + 2) % t.head_dim) >> 1;
-                        const float a0 = (float)pos * t.inv_freq[pr], a1 = (float)pos * t.inv_freq[pr1];
-                        double      s0, c0, s1, c1;
-                        sincos((double)a0, &s0, &c0);
-                        sincos((double)a1, &s1, &c1);
-                        const float2 p0 = rope_rotate(make_float2(sum.x, sum.y), make_float2((float)c0, (float)s0));
-                        const float2 p1 = rope_rotate(make_float2(sum.z, sum.w), make_float2((float)c1, (float)s1));
-                        o               = make_float4(p0.x, p0.y, p1.x, p1.y);
-                    }
-                    if (si == 0)
-                        *reinterpret_cast<float4 *>(sg.out + (int64_t)row * sg.ldo + col) = o;
-                    else {
-                        const int     blk = token_block(pos, t.bs_magic);
-                        const int     off = token_offset(pos, blk, t.block_size);
-                        const int     pb  = clamp_block(t.block_tables[(int64_t)row * t.max_blocks + blk], t.num_blocks);
-                        const int64_t at  = ((int64_t)pb * t.block_size + off) * t.row_len + col;
-                        *reinterpret_cast<float4 *>((si == 1 ? t.k_layer : t.v_layer) + at) = o;
-                    }
-                }
+            else if (whole) { // kSkinnyRope
+                const int si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
+                rope_append_store(p.rope, si, row, col, sum, sg.out + (int64_t)row * sg.ldo + col);
             }
         }
         return;
@@ -612,7 +621,13 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
                 sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
             }
             const int row = m0 + t * T + (T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * pt : 4 * pt + r);
-            if (row < p.m) {
+            if (EPI == kSkinnyRope) { // (T = 32; the host checked n % 4 == 0: a float4 is in or out)
+                if (row < p.m && col + 3 < sg.n) {
+                    const int si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
+                    rope_append_store(p.rope, si, row, col, sum, sg.out + (int64_t)row * sg.ldo + col);
+                }
+            }
+            else if (row < p.m) {
                 float *o = sg.out + (int64_t)row * sg.ldo + col;
                 if (col + 3 < sg.n && (sg.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.out) & 15) == 0))
                     *reinterpret_cast<float4 *>(o) = sum;
@@ -931,6 +946,18 @@ bool tile16(int batch, const int *n, int nseg, int cus)
            || (NVK_SKINNY16_WIDE && batch <= 64 && t32 <= cus / 4);
 }
 
+// the weight-streaming kernel's tile (16 or 32) and row tiles per wave for `batch` rows
+void skinny_choice(int batch, const int *n, int nseg, int cus, int *t, int *tm)
+{
+    *t = tile16(batch, n, nseg, cus) ? 16 : 32;
+    long long tiles = 0;
+    for (int s = 0; s < nseg; s++)
+        tiles += (n[s] + *t - 1) / *t;
+    // (several row tiles per wave only when the column tiles alone occupy the chip: with few columns, separate
+    //  workgroups per row tile are twice as many workgroups and faster -- 2560 columns x 64 rows: 15.9 us against 24.6)
+    *tm = (*t == 32 && NVK_SKINNY_TM && batch > 32 && tiles >= 128) ? (batch + 31) / 32 : 1;
+}
+
 int launch_linear(const float *in, int batch, int in_dim, const float *const *w, float *const *out, const int *n,
                   int nseg, int device, hipStream_t st, const char *who, bool glu = false,
                   const nvk::RopeAppendTarget *rope = nullptr, const nvk::NormLink *link = nullptr)
@@ -954,10 +981,12 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
     const int  cus = cu_count_of(device);
     const bool t16 = tile16(batch, n, nseg, cus);
-    // fused epilogues beyond the GEMV: the 16 x 16 tile kernel -- the norm link up to 16 rows, RoPE + append wherever
-    // that kernel is chosen up to 32 rows; SwiGLU only in the GEMV
+    // fused epilogues beyond the GEMV: the norm link in the 16 x 16 tile kernel up to 16 rows; RoPE + append wherever the
+    // weight-streaming kernel gives every row tile a workgroup of its own; SwiGLU only in the GEMV
+    int sk_t = 32, sk_tm = 1;
+    skinny_choice(batch, n, nseg, cus, &sk_t, &sk_tm);
     if (!gemv && (glu || (link && !(batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16))
-                  || (rope && !(t16 && batch <= 32))))
+                  || (rope && !(skinny && sk_tm == 1))))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: no fused epilogue for %d rows", who, batch);
     if ((rope || link) && !gemv) {
         for (int s = 0; s < nseg; s++)
@@ -1042,9 +1071,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     else if (skinny) {
         // 16 x 16 tiles up to 16 rows; 32 x 32 up to 32; above, one wave carries 2 or 3 row tiles of 32 (NVK_SKINNY_TM)
         const int t  = bn;
-        // (only when the column tiles alone occupy the chip: with few columns, separate workgroups per row tile are
-        //  twice as many workgroups and faster -- 2560 columns x 64 rows: 15.9 us against 24.6)
-        const int tm = (t == 32 && NVK_SKINNY_TM && batch > 32 && tiles >= 128) ? (batch + 31) / 32 : 1;
+        const int tm = sk_tm;
         const int bk = tm > 1 ? 32 : 64;
         p.m_tiles = tm > 1 ? 1 : (batch + t - 1) / t;
         const long long wgs = p.m_tiles == 1 ? tiles : (tiles + 7) / 8 * 8 * p.m_tiles;
@@ -1055,7 +1082,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         if (rope || link) { // the 16 x 16 tile kernel with an epilogue (checked above)
             using namespace nvk;
             const void *fused =
-                rope    ? (scale ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>
+                rope && t == 32 ? (const void *)nvk_gemm_skinny_kernel<32, 1, 64, kSkinnyRope, false>
+                : rope  ? (scale ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>
                                  : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>)
                 : resid ? (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyResid, false>
                         : (const void *)nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyPlain, true>;
@@ -1063,7 +1091,9 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             if (rc_lds != NVK_OK)
                 return rc_lds;
             const dim3 grid((unsigned)wgs); // (several row tiles only with the RoPE epilogue)
-            if (rope && scale)
+            if (rope && t == 32)
+                hipLaunchKernelGGL((nvk_gemm_skinny_kernel<32, 1, 64, kSkinnyRope, false>), grid, block, lds, st, p);
+            else if (rope && scale)
                 hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, true>), grid, block, lds, st, p);
             else if (rope)
                 hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyRope, false>), grid, block, lds, st, p);
@@ -1182,13 +1212,17 @@ int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x
 // can rows x (q_dim + 2 kv_dim) go through qkv_rope_append?
 bool nvk::qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim, int device)
 {
-    if (NVK_GEMV_COLS != 4 || NVK_GEMV_MAX_ROWS < 2 || NVK_SKINNY16_MAX_ROWS != 16 || rows < 1 || rows > 32 || dim % 4 != 0
-        || q_dim % 4 != 0 || kv_dim % 4 != 0)
+    if (NVK_GEMV_COLS != 4 || NVK_GEMV_MAX_ROWS < 2 || NVK_SKINNY16_MAX_ROWS != 16 || rows < 1 || rows > NVK_SKINNY_MAX_ROWS
+        || dim % 4 != 0 || q_dim % 4 != 0 || kv_dim % 4 != 0)
         return false;
-    // one or two rows: the GEMV (a pair inside a 4-column tile); up to 16: the 16 x 16 MFMA kernel; up to 32 where that
-    // kernel is the one chosen
+    // one or two rows: the GEMV (a pair inside a 4-column tile); more: the weight-streaming MFMA kernel wherever it gives
+    // every row tile a workgroup of its own
+    if (rows <= kFusedRowsMax)
+        return true;
     const int n[3] = {q_dim, kv_dim, kv_dim};
-    return rows <= kFusedRowsMax || tile16(rows, n, 3, cu_count_of(device));
+    int       t = 32, tm = 1;
+    skinny_choice(rows, n, 3, cu_count_of(device), &t, &tm);
+    return tm == 1;
 }
 
 extern "C" {

@@ -263,14 +263,15 @@ def test_layer_from_the_hidden_state():
                 fed[rid] += c
 
 
-@pytest.mark.parametrize("n_req", [1, 2, 5, 16, 27])
+@pytest.mark.parametrize("n_req", [1, 2, 5, 16, 27, 40, 70])
 def test_steps_of_few_decoding_rows_fuse_rope_and_append_into_the_projection(n_req):
-    """With up to 16 decoding rows (32 over few columns) nvk_batch_layer_hidden runs the q/k/v projections, RoPE and the KV append as ONE
+    """With up to 16 decoding rows (96 where every row tile of the product has a workgroup of its own: 16 x 16 tiles at
+    27 and 40 rows here, 32 x 32 at 70) nvk_batch_layer_hidden runs the q/k/v projections, RoPE and the KV append as ONE
     launch (the epilogue of the GEMV, or of the 16-row MFMA kernel, writes where nvk_rope_append_kernel would).  Same arithmetic: the attention output
     and every K/V block must equal, bit for bit, the piecewise path (nvk_qkv_project_device + nvk_batch_layer) run on
     a second pool with the same history."""
     L, H, KV, hd, bs, D = 2, 8, 2, 64, 8, 192
-    nb, max_blocks = 160, 8
+    nb, max_blocks = 320, 8
     rng = np.random.default_rng(92)
     sc = np.float32(1.0 / np.sqrt(D))
     W = [dict(g=rng.random(D, dtype=np.float32) + np.float32(0.5),
@@ -278,7 +279,7 @@ def test_steps_of_few_decoding_rows_fuse_rope_and_append_into_the_projection(n_r
               wk=rng.standard_normal((KV * hd, D), dtype=np.float32) * sc,
               wv=rng.standard_normal((KV * hd, D), dtype=np.float32) * sc) for _ in range(L)]
     ids = list(range(1, n_req + 1))
-    prompt = ([13, 6, 9, 3, 11, 1, 20, 7, 2, 15, 4, 8, 10, 5, 12, 14] * 2)[:n_req]
+    prompt = ([13, 6, 9, 3, 11, 1, 20, 7, 2, 15, 4, 8, 10, 5, 12, 14] * 5)[:n_req]
     xs = [[rng.standard_normal((sum(prompt) if s == 0 else n_req, D), dtype=np.float32) for _ in range(L)] for s in range(12)]
     outs, caches = [], []
     for fused in (True, False):
