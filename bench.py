@@ -185,6 +185,12 @@ def main():
     ap.add_argument("--replan", type=int, default=1,
                     help="rebuild the decode plan every N layer-calls inside the timed region "
                          "(1 = every call; 32 = as for the 32 layers of one model step)")
+    ap.add_argument("--plan", default="auto", choices=["auto", "kernel", "none"],
+                    help="auto: a batch whose sequences all have the same length is launched with NVK_DECODE_UNIFORM "
+                         "(no plan kernel: its order is the natural one), a ragged batch with the plan kernel; "
+                         "kernel: always build the plan; none: never (NVK_DECODE_NO_PLAN for ragged batches)")
+    ap.add_argument("--merge", default="auto", choices=["auto", "kernel", "separate"],
+                    help="split-K combine: the library's choice, inside the decode kernel, or nvk_merge_kernel")
     ap.add_argument("--strong", action="store_true",
                     help="sequence-sharded strong scaling: ONE batch of the workload's shape is split over the ranks "
                          "by context tokens (sharding.partition_sequences) instead of one batch per rank")
@@ -232,6 +238,13 @@ def main():
             else wl.Workload(work.name + f"_part{rank}of{world}", g, work.num_blocks, work.ctx_lens[mine],
                              work.block_tables[mine], False)
     flags = {"auto": nv.AUTO, "single": nv.SINGLE_PASS, "split": nv.SPLIT_K}[args.mode]
+    flags |= {"auto": 0, "kernel": nv.MERGE_IN_KERNEL, "separate": nv.MERGE_SEPARATE}[args.merge]
+    uniform_batch = bool((work.ctx_lens == work.ctx_lens[0]).all())
+    if args.plan == "none" or (args.plan == "auto" and uniform_batch):
+        flags |= nv.UNIFORM if uniform_batch else nv.NO_PLAN
+    planning = ("none: uniform lengths, natural chunk order" if flags & nv.UNIFORM else
+                "none: lengths read by the decode kernel, natural chunk order" if flags & nv.NO_PLAN else
+                f"nvk_plan_kernel, rebuilt every {args.replan} layer-call(s)")
 
     def barrier():
         if world > 1:
@@ -334,7 +347,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": work.name, "num_seqs_per_gpu": work.num_seqs, "total_ctx_tokens_per_gpu":
                        work.total_tokens, "n_heads": g.n_heads, "n_kv_heads": g.n_kv_heads, "head_dim": g.head_dim,
-                       "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode, "replan_every": args.replan,
+                       "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode, "replan_every": args.replan, "plan": planning,
+                       "merge": args.merge,
                        "parallelism": (f"sequence-sharded x{world}, no collective" if args.shard == "seq" else
                                        f"head-sharded x{world}, one RCCL all-gather of out per layer-call")},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),

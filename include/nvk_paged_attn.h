@@ -40,6 +40,18 @@ extern "C" {
 #define NVK_DECODE_AUTO 0        /* library picks chunking from the batch shape      */
 #define NVK_DECODE_SINGLE_PASS 1 /* one chunk per sequence, no workspace, no merge   */
 #define NVK_DECODE_SPLIT_K 2     /* flash-decoding: chunk_tokens per workgroup+merge */
+/* modifiers, OR-ed onto the mode above (default: the library decides).
+ * Where a sequence is cut into chunks, the chunks' partial (max, sum, output) triples are combined as the
+ * reference's softmax would have (include/core/attention.hpp:126-140).  Up to 16 chunks per sequence that
+ * happens inside the decode kernel -- the workgroup that finishes a sequence's last outstanding chunk merges
+ * them -- beyond that by a merge kernel that spreads a sequence's chunks over many CUs.  Same bits either way
+ * for the chunk-ordered form (MERGE_SEPARATE), which the tests hold the in-kernel form to. */
+#define NVK_DECODE_MERGE_IN_KERNEL 0x100 /* combine inside the decode kernel whatever the chunk count      */
+#define NVK_DECODE_MERGE_SEPARATE 0x200  /* combine by nvk_merge_kernel (one thread per output float4)     */
+/* The work list (plan) only ORDERS the chunks, longest first; for a batch whose sequences all have the same
+ * length that order is the natural one and the plan kernel is skipped: */
+#define NVK_DECODE_UNIFORM 0x400 /* every sequence holds exactly max_ctx tokens; ctx_lens_dev may be NULL   */
+#define NVK_DECODE_NO_PLAN 0x800 /* ragged lengths, read by the decode kernel itself; natural chunk order   */
 
 /* prefill flags */
 #define NVK_PREFILL_AUTO 0    /* library picks by chunk length                                      */
@@ -257,7 +269,8 @@ int nvk_decode_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const fl
  * nvk_decode_device; L = once per L calls, as for the L layers of a model step).
  *   total_ms  region time / iters (plan + attention + merge kernels + gaps)
  *   attn_ms   mean over the same region of the attention kernel's own
- *             duration, from an event pair around every 8th of its launches
+ *             duration, from an event pair around each of its launches
+ *             (around every 8th when iters > 32)
  * Either may be NULL; iters == 0 only warms up.  Returns after the region has
  * finished on the device. */
 int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,

@@ -23,6 +23,10 @@ ERR_UNBOUND = -6
 DECODE_AUTO = 0
 DECODE_SINGLE_PASS = 1
 DECODE_SPLIT_K = 2
+DECODE_MERGE_IN_KERNEL = 0x100
+DECODE_MERGE_SEPARATE = 0x200
+DECODE_UNIFORM = 0x400
+DECODE_NO_PLAN = 0x800
 
 PREFILL_AUTO = 0
 PREFILL_ROWWISE = 1

@@ -21,6 +21,11 @@ from .kv_pool import PagedKVPool, _devptr, _f32, _i32, _ptr
 AUTO = _capi.DECODE_AUTO
 SINGLE_PASS = _capi.DECODE_SINGLE_PASS
 SPLIT_K = _capi.DECODE_SPLIT_K
+# modifiers, OR-ed onto a mode (include/nvk_paged_attn.h)
+MERGE_IN_KERNEL = _capi.DECODE_MERGE_IN_KERNEL
+MERGE_SEPARATE = _capi.DECODE_MERGE_SEPARATE
+UNIFORM = _capi.DECODE_UNIFORM
+NO_PLAN = _capi.DECODE_NO_PLAN
 
 
 def bind_pool(pool: Optional[PagedKVPool], layer: int = 0) -> None:

@@ -58,14 +58,13 @@ static_assert(NVK_STEP_TOKENS % 4 == 0 && NVK_STEP_TOKENS >= 4, "a step is whole
 #ifndef NVK_TPL_VPL1
 #define NVK_TPL_VPL1 4 // tokens per lane per step for rows of <= 64 floats (twice the others: same bytes in flight)
 #endif
-// (7 or 8 q-heads over rows of more than 64 floats: q and the accumulators take 128 registers, so the tiles
-// shrink to one token per lane -- half the bytes in flight, but K/V are read once instead of twice)
-constexpr int tok_per_lane(int vpl, int qpk) { return vpl == 1 ? NVK_TPL_VPL1 : (qpk > 6 ? 1 : NVK_STEP_TOKENS / 4); }
+constexpr int tok_per_lane(int vpl, int qpk) { return vpl == 1 ? NVK_TPL_VPL1 : NVK_STEP_TOKENS / 4; }
 constexpr int step_tokens(int vpl, int qpk) { return 4 * tok_per_lane(vpl, qpk); }
-// Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) for rows of up to 128 floats; 4 (one per SIMD,
-// the whole register file) for 256-float rows, whose q, accumulators and two tiles for all four q-heads
-// of a group need about 300 registers -- cheaper than reading K/V once per q-head pair.
-constexpr int wg_waves(int vpl) { return vpl >= 4 ? 4 : 8; }
+// Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) where q, the accumulators and two tiles fit 256
+// registers; 4 (one per SIMD, the whole register file: values the VALU is not working on sit in AGPRs) where
+// they do not -- 256-float rows, and 128-float rows with 7 or 8 q-heads per wave (6 when head_dim < 128 adds
+// the load predicates).  Cheaper than reading K/V once per q-head sub-group, and no scratch.
+constexpr int wg_waves(int vpl, int qpk, bool full) { return vpl >= 4 || (vpl == 2 && qpk >= (full ? 7 : 6)) ? 4 : 8; }
 constexpr float kNegBig     = -1.0e30f; // running-max seed: finite, so exp2(m - m) never sees inf - inf
 // The reference seeds its max with -1e10 (attention.hpp:126); in the exp2
 // domain that floor is -1e10 * log2(e).
@@ -107,7 +106,29 @@ struct DecodeParams
     int             merge_off; // int offset of the token-split merge area behind the table slice in LDS
     int             items_padded; // item slots per (kv-head group, q sub-group): the item bound, a multiple of 8 when qsplit > 1
     float           q_scale;   // log2(e) / sqrt(head_dim)
+    // Direct indexing (no plan): item i is chunk i % max_chunks of sequence i / max_chunks, its length read from
+    // ctx_lens on the spot (null: every sequence holds uniform_ctx tokens).  For batches whose lengths are all
+    // equal the plan's order IS this order, so nvk_plan_kernel has nothing to add.
+    int             direct;
+    int             num_seqs;
+    int             chunk_tokens;
+    int             uniform_ctx;
+    const int      *ctx_lens;
+    // Split-K combine inside this kernel: one arrival counter per (sequence, kv-head group x q sub-group), zero
+    // between launches; the workgroup whose arrival completes a sequence's chunks merges them (null: the partials
+    // are left for nvk_merge_kernel / nvk_merge_wide_kernel).
+    int            *arrivals;
+#ifdef NVK_STAMPS // diagnostic build: eight 100 MHz timestamps per workgroup (tools/wg_timeline.py)
+    unsigned long long *stamps;
+#endif
 };
+#ifdef NVK_STAMPS
+#define NVK_STAMP(i)                                                                                                   \
+    if (p.stamps && threadIdx.x == 0)                                                                                  \
+        p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define NVK_STAMP(i)
+#endif
 
 // ---- wave-level helpers ---------------------------------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_move(float x)
@@ -251,6 +272,51 @@ __global__ void __launch_bounds__(kPlanThreads)
         *n_items = n_full + n_part;
 }
 
+// ---- split-K combine of one (row, q-head, float4) --------------------------------
+// Log-sum-exp merge of a row's chunk partials in chunk order, then the reference's normalisation
+// (attention.hpp:126-140 with its -1e10 floor on the maximum).  The ONE definition of the combine's arithmetic:
+// nvk_merge_kernel runs it a thread per output float4, nvk_decode_kernel runs it in the workgroup that completes
+// a sequence, and the two give the same bits.  Loads go four chunks ahead of the (serial) sums.
+__device__ __forceinline__ void merge_chunks(const float *ws_o, const float *ws_ml, float *out, int64_t row, int head,
+                                             int vec, int nch, int n_heads, int head_dim, int max_chunks)
+{
+    const float  *ml = ws_ml + (row * max_chunks * n_heads + head) * 2;
+    const float  *po = ws_o + (row * max_chunks * n_heads + head) * head_dim + 4 * vec;
+    const int64_t ml_step = (int64_t)n_heads * 2, o_step = (int64_t)n_heads * head_dim;
+
+    float top = kRefMaxFloorLog2; // the reference's -1e10 floor, see nvk_decode_kernel
+    for (int c = 0; c < nch; c++)
+        top = fmaxf(top, ml[c * ml_step]);
+    float  denom = 0.f;
+    float4 acc   = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto   add   = [&](const float2 &s, const float4 &a) {
+        const float f = fast_exp2(s.x - top);
+        denom         = fmaf(s.y, f, denom);
+        acc.x         = fmaf(a.x, f, acc.x);
+        acc.y         = fmaf(a.y, f, acc.y);
+        acc.z         = fmaf(a.z, f, acc.z);
+        acc.w         = fmaf(a.w, f, acc.w);
+    };
+    int c = 0;
+    for (; c + 4 <= nch; c += 4) {
+        float2 s[4];
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s[u] = *reinterpret_cast<const float2 *>(ml + (c + u) * ml_step);
+            a[u] = *reinterpret_cast<const float4 *>(po + (c + u) * o_step);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            add(s[u], a[u]);
+    }
+    for (; c < nch; c++)
+        add(*reinterpret_cast<const float2 *>(ml + c * ml_step), *reinterpret_cast<const float4 *>(po + c * o_step));
+    const float inv = 1.0f / denom;
+    *reinterpret_cast<float4 *>(out + (row * n_heads + head) * head_dim + 4 * vec) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
 // ---- the decode kernel ----------------------------------------------------
 // VPL   float4 per lane per row (head_dim <= 64*VPL)
 // QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.y also walks kv_mul/QPK)
@@ -262,7 +328,8 @@ __global__ void __launch_bounds__(kPlanThreads)
 // wave w takes sub-range w / kv_waves, and the sub-ranges are merged through LDS at the end, so a
 // workgroup keeps 8 waves of loads in flight whatever the head count.
 template <int VPL, int QPK, bool FULL>
-__global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_decode_kernel(const DecodeParams p)
+__global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_PER_EU)
+    nvk_decode_kernel(const DecodeParams p)
 {
     constexpr int kTokPerLane = tok_per_lane(VPL, QPK); // tokens each lane holds per step
     constexpr int kStepTokens = step_tokens(VPL, QPK);  // tokens per wave per pipeline step
@@ -273,6 +340,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     // group has more q-heads than one wave carries) read the very same K/V bytes: ids are dealt in blocks of
     // 8 * qsplit so that id and id + 8 are the same item, and -- workgroup ids going round-robin over the 8 XCDs --
     // they run on one XCD at about the same time and meet in its L2.
+    NVK_STAMP(0)
     const int qsplit = p.kv_mul / QPK;
     const int inner  = p.items_padded * qsplit; // workgroups per kv-head group
     const int kvg    = blockIdx.x / inner;
@@ -282,14 +350,25 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
         item_i         = item_i / span * 8 + rem % 8;
         zq             = rem / 8;
     }
-    if (item_i >= *p.n_items)
-        return;
-    const WorkItem item  = p.items[item_i];
-    const int      seq   = item.seq;
-    const int      chunk = item.w & 0xFFFF;
-    const int      nch   = item.w >> 16; // chunks of this sequence: 1 -> this workgroup writes `out` itself
-    const int      t0    = item.t0;
-    const int      t1    = item.t1;
+    int seq, chunk, nch = 0, t0, t1 = 0, ctx_raw = 0; // nch: chunks of this sequence; 1 -> this workgroup writes `out` itself
+    if (p.direct) {
+        if (item_i >= p.num_seqs * p.max_chunks)
+            return;
+        seq     = item_i / p.max_chunks;
+        chunk   = item_i - seq * p.max_chunks;
+        t0      = chunk * p.chunk_tokens;
+        ctx_raw = p.ctx_lens ? p.ctx_lens[seq] : p.uniform_ctx; // used only after the q and table loads are on their way
+    }
+    else {
+        if (item_i >= *p.n_items)
+            return;
+        const WorkItem item = p.items[item_i];
+        seq = item.seq, chunk = item.w & 0xFFFF, nch = item.w >> 16, t0 = item.t0, t1 = item.t1;
+    }
+    // wave-uniform by construction (functions of blockIdx and of scalar loads); say so, for the buffer
+    // descriptors and the branches below
+    seq = __builtin_amdgcn_readfirstlane(seq), chunk = __builtin_amdgcn_readfirstlane(chunk);
+    t0  = __builtin_amdgcn_readfirstlane(t0);
 
     const int lane   = threadIdx.x & 63;
     const int wave   = threadIdx.x >> 6;
@@ -297,7 +376,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
     const int slot   = lane >> 4; // which token of a quad
     const int r      = lane & 15; // which 16 B of a 256-B row piece
 
-    // blockIdx.y enumerates (kv-head group, q sub-group); waves enumerate kv-heads in the group
+    // waves enumerate the kv-heads of the group (and, with fewer kv-heads than waves, the token parts)
     const int  parts  = nwaves / p.kv_waves; // token-split factor (1 when the group has 8 kv-heads)
     const int  part   = wave / p.kv_waves;
     const int  kvh    = kvg * p.kv_waves + wave % p.kv_waves;
@@ -309,6 +388,42 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
 #pragma unroll
     for (int j = 0; j < VPL; j++)
         act[j] = FULL || (64 * j + 4 * r < hd);
+
+    // q for this wave's q-heads: issued before the table staging so both latencies overlap
+    float4 qv[QPK][VPL];
+#pragma unroll
+    for (int h = 0; h < QPK; h++)
+#pragma unroll
+        for (int j = 0; j < VPL; j++) {
+            qv[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && act[j])
+                qv[h][j] = *reinterpret_cast<const float4 *>(p.q + ((int64_t)seq * p.n_heads + qh0 + h) * hd
+                                                             + 64 * j + 4 * r);
+        }
+
+    // the chunk's slice of the block table -> LDS.  With a plan the slice ends at the chunk's last token; without
+    // one the length is still on its way, so the whole chunk's range is staged (entries past a sequence's end are
+    // padding of its row: readable, clamped, never used).
+    const int blk0 = token_block(t0, p.bs_magic);
+    const int blk_last = p.direct ? min(token_block(t0 + p.chunk_tokens - 1, p.bs_magic), p.max_blocks - 1)
+                                  : (t1 > t0 ? token_block(t1 - 1, p.bs_magic) : blk0 - 1);
+#ifdef NVK_NO_TABLE_ROWS // A/B build: the decode kernel without the prefill indirection
+    const int trow = seq;
+#else
+    const int trow = p.table_rows ? p.table_rows[seq] : seq;
+#endif
+    for (int i = threadIdx.x; i <= blk_last - blk0; i += blockDim.x)
+        s_tab[i] = clamp_block(p.block_tables[(int64_t)trow * p.max_blocks + blk0 + i], p.num_blocks);
+    if (p.direct) {
+        const int ctx = min(max(ctx_raw, 0), p.max_chunks * p.chunk_tokens);
+        nch           = (ctx + p.chunk_tokens - 1) / p.chunk_tokens;
+        t1            = min(ctx, t0 + p.chunk_tokens);
+        if (chunk >= max(nch, 1))
+            return; // the sequence ends before this chunk (an empty sequence keeps chunk 0: it zeroes the row)
+    }
+    nch = __builtin_amdgcn_readfirstlane(nch), t1 = __builtin_amdgcn_readfirstlane(t1);
+    __syncthreads();
+    NVK_STAMP(1)
 
     if (t1 <= t0) {
         // a sequence with no context: the reference zeroes `out` and does nothing else (attention.hpp:98)
@@ -323,31 +438,11 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
         }
         return;
     }
-
-    // q for this wave's q-heads: issued before the table staging so both latencies overlap
-    float4 qv[QPK][VPL];
-#pragma unroll
-    for (int h = 0; h < QPK; h++)
-#pragma unroll
-        for (int j = 0; j < VPL; j++) {
-            qv[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live && act[j])
-                qv[h][j] = *reinterpret_cast<const float4 *>(p.q + ((int64_t)seq * p.n_heads + qh0 + h) * hd
-                                                             + 64 * j + 4 * r);
-        }
-
-    const int blk0 = token_block(t0, p.bs_magic);
-    const int blk1 = token_block(t1 - 1, p.bs_magic);
-#ifdef NVK_NO_TABLE_ROWS // A/B build: the decode kernel without the prefill indirection
-    const int trow = seq;
-#else
-    const int trow = p.table_rows ? p.table_rows[seq] : seq;
-#endif
-    for (int i = threadIdx.x; i <= blk1 - blk0; i += blockDim.x)
-        s_tab[i] = clamp_block(p.block_tables[(int64_t)trow * p.max_blocks + blk0 + i], p.num_blocks);
-    __syncthreads();
-    if (!live)
-        return; // dead waves exist only in groups of 8 kv-waves, which have no second barrier (parts == 1)
+    // split-K combine in this kernel: every wave of the workgroup stays to the end (the arrival protocol has
+    // two barriers); otherwise waves without a kv-head leave now (they exist only when parts == 1: no barrier follows)
+    const bool fused = p.arrivals != nullptr && nch > 1;
+    if (!live && !fused)
+        return;
 
     // this wave's share of the chunk: whole steps
     int w0 = t0, w1 = t1, stride = kStepTokens;
@@ -366,7 +461,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
         nsteps = nsteps > part ? (nsteps - part + parts - 1) / parts : 0;
 #endif
     }
-    const bool has_tokens = nsteps > 0;
+    const bool has_tokens = live && nsteps > 0;
 
     // pre-scale q into the exp2 domain
 #pragma unroll
@@ -495,6 +590,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
         }
     }
 
+    NVK_STAMP(2)
     // merge the four token slots of the wave (lanes 16 and 32 apart)
 #pragma unroll
     for (int h = 0; h < QPK; h++) {
@@ -534,9 +630,9 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
             }
         }
         __syncthreads();
-        if (part > 0)
+        if (part > 0 && !fused)
             return;
-        if (slot == 0) {
+        if (slot == 0 && part == 0) {
 #pragma unroll
             for (int h = 0; h < QPK; h++) {
                 float mw = m[h];
@@ -567,10 +663,11 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
         }
     }
 
-    if (slot != 0)
-        return;
+    const bool writer = live && slot == 0 && part == 0; // the lanes that hold the chunk's (m, l, o)
 
     if (nch == 1) {
+        if (!writer)
+            return;
 #pragma unroll
         for (int h = 0; h < QPK; h++) {
             // reference: max_val = max(-1e10, scores) (attention.hpp:126-130); a no-op unless every score is below it
@@ -583,20 +680,71 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
                     *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
                         make_float4(o[h][j].x * inv, o[h][j].y * inv, o[h][j].z * inv, o[h][j].w * inv);
         }
+        return;
     }
-    else {
+
+    // The chunk's unnormalised partial goes to its slab of the workspace, write-through (sc1): the bytes are on
+    // their way to memory when the store completes, so the workgroup that combines the sequence -- on whichever
+    // XCD it runs -- needs no release fence from this one, only the arrival below.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int kSc1 = 16; // aux bit 4 of the buffer instructions on gfx950
+    if (writer) {
         const int64_t slab = (int64_t)seq * p.max_chunks + chunk;
+        const __amdgpu_buffer_rsrc_t rs_o =
+            __builtin_amdgcn_make_buffer_rsrc(p.ws_o + slab * p.n_heads * hd, 0, p.n_heads * hd * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ml =
+            __builtin_amdgcn_make_buffer_rsrc(p.ws_ml + slab * p.n_heads * 2, 0, p.n_heads * 8, 0x00020000);
 #pragma unroll
         for (int h = 0; h < QPK; h++) {
 #pragma unroll
             for (int j = 0; j < VPL; j++)
                 if (act[j])
-                    *reinterpret_cast<float4 *>(p.ws_o + (slab * p.n_heads + qh0 + h) * hd + 64 * j + 4 * r) =
-                        o[h][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[h][j]), rs_o,
+                                                           ((qh0 + h) * hd + 64 * j + 4 * r) * 4, 0, kSc1);
             if (r == 0)
-                *reinterpret_cast<float2 *>(p.ws_ml + (slab * p.n_heads + qh0 + h) * 2) = make_float2(m[h], l[h]);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(m[h], l[h])), rs_ml,
+                                                      (qh0 + h) * 8, 0, kSc1);
         }
     }
+    if (!fused)
+        return;
+
+    // ---- split-K combine by the workgroup that arrives last (cdna_hip_programming.md, Guideline 16) ----
+    // Every storing wave drains its write-through stores, the workgroup meets, ONE lane adds the arrival
+    // (agent scope).  Whoever draws nch - 1 knows every chunk of the sequence has been written through:
+    // one agent-scope acquire (drops this CU's stale lines), its wait, a barrier, then plain loads.  Nobody
+    // waits for anybody: no spin, no residency assumption, any placement of the chunks over XCDs.
+    NVK_STAMP(3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    NVK_STAMP(4)
+    const int qgroups = gridDim.x / p.items_padded; // (kv-head group, q sub-group) pairs = arrival counters per sequence
+    if (threadIdx.x == 0) {
+        int *cnt       = p.arrivals + (int64_t)seq * qgroups + (kvg * qsplit + zq);
+        const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == nch - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // zero again for the next launch
+        }
+        s_tab[0] = last; // the table slice is dead: every wave is past its loop
+    }
+    __syncthreads();
+    NVK_STAMP(5)
+    if (!s_tab[0])
+        return;
+    const int vec_row = hd >> 2;
+    const int n_mine  = p.kv_waves * QPK * vec_row; // (q-head, float4) pairs of this workgroup's heads
+    for (int idx = threadIdx.x; idx < n_mine; idx += blockDim.x) {
+        const int hh = idx / vec_row, vec = idx - hh * vec_row;
+        const int w = hh / QPK, kvh_w = kvg * p.kv_waves + w;
+        if (kvh_w < p.n_kv_heads)
+            merge_chunks(p.ws_o, p.ws_ml, p.out, seq, kvh_w * p.kv_mul + zq * QPK + (hh - w * QPK), vec, nch, p.n_heads,
+                         hd, p.max_chunks);
+    }
+    NVK_STAMP(6)
 }
 
 // ---- split-K merge (flash-decoding combine) ---------------------------------
@@ -604,13 +752,25 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL), NVK_MIN_WAVES_PER_EU) nvk_
 // the sequence's chunk partials, in chunk order, then the reference's
 // normalisation.  Sequences with at most one chunk were finished by
 // nvk_decode_kernel and are skipped.
+// Chunks of row `seq`: from the plan's per-row counts, or -- no plan -- from the row's length (null: uniform_ctx).
+__device__ __forceinline__ int row_chunks(const int *seq_chunks, const int *ctx_lens, int uniform_ctx, int chunk_tokens,
+                                          int max_chunks, int seq)
+{
+    if (seq_chunks)
+        return min(seq_chunks[seq], max_chunks);
+    const int ctx = max(ctx_lens ? ctx_lens[seq] : uniform_ctx, 0);
+    return (int)min((int64_t)max_chunks, ((int64_t)ctx + chunk_tokens - 1) / chunk_tokens);
+}
+
 __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict__ ws_o,
                                                         const float *__restrict__ ws_ml,
-                                                        const int *__restrict__ seq_chunks, float *__restrict__ out,
-                                                        int n_heads, int head_dim, int max_chunks)
+                                                        const int *__restrict__ seq_chunks,
+                                                        const int *__restrict__ ctx_lens, int uniform_ctx,
+                                                        int chunk_tokens, float *__restrict__ out, int n_heads,
+                                                        int head_dim, int max_chunks)
 {
     const int seq = blockIdx.x; // rows on x: no 65535 limit on the batch
-    const int nch = min(seq_chunks[seq], max_chunks);
+    const int nch = row_chunks(seq_chunks, ctx_lens, uniform_ctx, chunk_tokens, max_chunks, seq);
     if (nch <= 1)
         return;
     const int vec_row = head_dim >> 2; // float4 per head
@@ -620,27 +780,7 @@ __global__ void __launch_bounds__(256) nvk_merge_kernel(const float *__restrict_
     const int head = idx / vec_row;
     const int vec  = idx - head * vec_row;
 
-    const float *ml = ws_ml + ((int64_t)seq * max_chunks * n_heads + head) * 2;
-    const float *po = ws_o + ((int64_t)seq * max_chunks * n_heads + head) * head_dim + 4 * vec;
-
-    float top = kRefMaxFloorLog2; // the reference's -1e10 floor, see nvk_decode_kernel
-    for (int c = 0; c < nch; c++)
-        top = fmaxf(top, ml[(int64_t)c * n_heads * 2]);
-    float  denom = 0.f;
-    float4 acc   = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < nch; c++) {
-        const float2 s = *reinterpret_cast<const float2 *>(ml + (int64_t)c * n_heads * 2);
-        const float  f = fast_exp2(s.x - top);
-        const float4 a = *reinterpret_cast<const float4 *>(po + (int64_t)c * n_heads * head_dim);
-        denom          = fmaf(s.y, f, denom);
-        acc.x          = fmaf(a.x, f, acc.x);
-        acc.y          = fmaf(a.y, f, acc.y);
-        acc.z          = fmaf(a.z, f, acc.z);
-        acc.w          = fmaf(a.w, f, acc.w);
-    }
-    const float inv = 1.0f / denom;
-    *reinterpret_cast<float4 *>(out + ((int64_t)seq * n_heads + head) * head_dim + 4 * vec) =
-        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    merge_chunks(ws_o, ws_ml, out, seq, head, vec, nch, n_heads, head_dim, max_chunks);
 }
 
 // ---- split-K merge for few rows and many chunks ------------------------------
@@ -654,14 +794,16 @@ constexpr int kMergeWideMaxChunks = 256;
 
 __global__ void __launch_bounds__(256) nvk_merge_wide_kernel(const float *__restrict__ ws_o,
                                                              const float *__restrict__ ws_ml,
-                                                             const int *__restrict__ seq_chunks, float *__restrict__ out,
-                                                             int n_heads, int head_dim, int max_chunks)
+                                                             const int *__restrict__ seq_chunks,
+                                                             const int *__restrict__ ctx_lens, int uniform_ctx,
+                                                             int chunk_tokens, float *__restrict__ out, int n_heads,
+                                                             int head_dim, int max_chunks)
 {
     __shared__ float  s_f[kMergeWideMaxChunks];
     __shared__ float  s_red[8];
     __shared__ float4 s_acc[256];
     const int seq = blockIdx.x, head = blockIdx.y;
-    const int nch = min(seq_chunks[seq], max_chunks); // uniform over the workgroup
+    const int nch = row_chunks(seq_chunks, ctx_lens, uniform_ctx, chunk_tokens, max_chunks, seq); // uniform over the workgroup
     if (nch <= 1)
         return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -39,6 +39,11 @@
 #ifndef NVK_AUTO_MAX_CHUNK
 #define NVK_AUTO_MAX_CHUNK 2048 // longest chunk NVK_DECODE_AUTO picks
 #endif
+#ifndef NVK_FUSE_MAX_CHUNKS
+#define NVK_FUSE_MAX_CHUNKS 16 // chunks per sequence up to which the split-K combine runs inside the decode kernel (the
+                               // workgroup that completes a sequence merges it: one CU's worth of reading, fine for a
+                               // few chunks); beyond that the merge kernels spread a sequence's chunks over many CUs
+#endif
 
 // ------------------------------------------------------------------ errors
 namespace nvk {
@@ -92,6 +97,10 @@ struct nvk_pool
     float *ws_o = nullptr, *ws_ml = nullptr;
     size_t ws_o_floats = 0, ws_ml_floats = 0;
     long long ws_generation = 0; // bumped whenever the workspace moves (captured graphs hold its address)
+    // arrival counters of the in-kernel split-K combine: [rows, kv-head groups x q sub-groups], zero between
+    // launches (zeroed when allocated; the workgroup that completes a row zeroes its counter again)
+    int   *arrivals     = nullptr;
+    size_t arrivals_cap = 0;
 
     // the plan nvk_decode / nvk_decode_device rebuild on every call (callers that
     // reuse one plan across the layers of a model step own an nvk_plan instead)
@@ -155,28 +164,51 @@ int ensure_pin(nvk_pool *pool, size_t bytes)
     return NVK_OK;
 }
 
-int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats)
+// A buffer that has to grow is freed and allocated again: never while `stream` is being captured into a graph
+// (hipFree / hipMalloc / a device-wide wait are not capturable, and the graph would keep the old address).
+// Refused before anything is touched, with the remedy in the message.
+int refuse_growth_under_capture(hipStream_t stream, const char *what)
 {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        return nvk::fail(NVK_ERR_INVALID_ARG,
+                         "%s would have to grow while the stream is being captured: size it first, outside the capture "
+                         "(nvk_pool_reserve_workspace, or one direct call of the same shape)", what);
+    return NVK_OK;
+}
+
+int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats, size_t arrival_ints, hipStream_t stream)
+{
+    if (o_floats <= pool->ws_o_floats && ml_floats <= pool->ws_ml_floats && arrival_ints <= pool->arrivals_cap)
+        return NVK_OK;
+    int rc = refuse_growth_under_capture(stream, "the split-K workspace");
+    if (rc != NVK_OK)
+        return rc;
+    HIP_TRY(hipDeviceSynchronize()); // launches on any stream may still use the old buffers
     if (o_floats > pool->ws_o_floats) {
-        if (pool->ws_o) {
-            HIP_TRY(hipDeviceSynchronize());
+        if (pool->ws_o)
             HIP_TRY(hipFree(pool->ws_o));
-            pool->ws_o        = nullptr;
-            pool->ws_o_floats = 0;
-        }
+        pool->ws_o = nullptr, pool->ws_o_floats = 0;
         HIP_TRY(hipMalloc(&pool->ws_o, o_floats * sizeof(float)));
         pool->ws_o_floats = o_floats;
         pool->ws_generation++;
     }
     if (ml_floats > pool->ws_ml_floats) {
-        if (pool->ws_ml) {
-            HIP_TRY(hipDeviceSynchronize());
+        if (pool->ws_ml)
             HIP_TRY(hipFree(pool->ws_ml));
-            pool->ws_ml        = nullptr;
-            pool->ws_ml_floats = 0;
-        }
+        pool->ws_ml = nullptr, pool->ws_ml_floats = 0;
         HIP_TRY(hipMalloc(&pool->ws_ml, ml_floats * sizeof(float)));
         pool->ws_ml_floats = ml_floats;
+        pool->ws_generation++;
+    }
+    if (arrival_ints > pool->arrivals_cap) {
+        if (pool->arrivals)
+            HIP_TRY(hipFree(pool->arrivals));
+        pool->arrivals = nullptr, pool->arrivals_cap = 0;
+        const size_t want = std::max(arrival_ints, (size_t)4096);
+        HIP_TRY(hipMalloc(&pool->arrivals, want * sizeof(int)));
+        HIP_TRY(hipMemset(pool->arrivals, 0, want * sizeof(int)));
+        pool->arrivals_cap = want;
         pool->ws_generation++;
     }
     return NVK_OK;
@@ -211,6 +243,10 @@ int check_pool_layer(const nvk_pool *pool, int layer, const char *who)
     return NVK_OK;
 }
 
+#ifdef NVK_STAMPS
+unsigned long long *g_debug_stamps = nullptr; // diagnostic build only: [workgroups, 8] device buffer
+#endif
+
 // ------------------------------------------------------------ launch plan
 struct LaunchShape
 {
@@ -224,14 +260,30 @@ struct LaunchShape
     int vpl          = 1;
     bool full        = false;
     size_t lds_bytes = 0;
+    int  qgroups     = 1;     // (kv-head group, q sub-group) pairs per item = arrival counters per row
+    bool fuse_merge  = false; // max_chunks > 1: the decode kernel combines a row's chunks itself
+    bool force_serial_merge = false; // NVK_DECODE_MERGE_SEPARATE: nvk_merge_kernel whatever the shape
 };
+
+// flags = mode (low byte) | modifiers
+bool decode_flags_ok(int flags)
+{
+    const int mode = flags & 0xff, mods = flags & ~0xff;
+    if (mode != NVK_DECODE_AUTO && mode != NVK_DECODE_SINGLE_PASS && mode != NVK_DECODE_SPLIT_K)
+        return false;
+    if (mods & ~(NVK_DECODE_MERGE_IN_KERNEL | NVK_DECODE_MERGE_SEPARATE | NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN))
+        return false;
+    return !((mods & NVK_DECODE_MERGE_IN_KERNEL) && (mods & NVK_DECODE_MERGE_SEPARATE));
+}
 
 constexpr int kMaxTableSliceEntries = 8192; // 32 KiB of LDS per workgroup at most
 
 int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens,
                LaunchShape *plan)
 {
-    const int hd = pool->head_dim;
+    const int hd   = pool->head_dim;
+    const int mods = flags & ~0xff;
+    flags &= 0xff;
     if (n_heads <= 0 || n_heads % pool->n_kv_heads != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "n_heads=%d is not a positive multiple of n_kv_heads=%d", n_heads,
                          pool->n_kv_heads);
@@ -249,7 +301,7 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
             plan->qpk = d;
             break;
         }
-    const int wg_waves = std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl));
+    const int wg_waves = std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl, plan->qpk, plan->full));
     plan->waves      = std::min(pool->n_kv_heads, wg_waves);
     plan->kv_groups  = (pool->n_kv_heads + plan->waves - 1) / plan->waves;
     // fewer kv-heads than a workgroup has waves (a head-sharded rank, a small model): the other waves split
@@ -301,6 +353,10 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int);
     if (plan->parts > 1)
         plan->lds_bytes += (size_t)plan->waves * plan->parts * plan->qpk * (4 + plan->vpl * 64) * sizeof(float);
+    plan->qgroups            = plan->kv_groups * (kv_mul / plan->qpk);
+    plan->force_serial_merge = (mods & NVK_DECODE_MERGE_SEPARATE) != 0;
+    plan->fuse_merge         = plan->max_chunks > 1 && !plan->force_serial_merge
+                       && ((mods & NVK_DECODE_MERGE_IN_KERNEL) || plan->max_chunks <= NVK_FUSE_MAX_CHUNKS);
     return NVK_OK;
 }
 
@@ -357,12 +413,21 @@ struct nvk_plan
     int          *counters = nullptr; // [0] = n_items, [1 + s] = chunks of sequence s
     size_t        cap_items = 0, cap_seqs = 0;
     int           item_bound = 0; // grid.x: at least as many workgroups as items
+    // direct indexing (NVK_DECODE_UNIFORM / NVK_DECODE_NO_PLAN): no work list; the kernels read the lengths themselves
+    bool          direct = false;
+    const int    *ctx_lens_dev = nullptr; // direct: the caller's lengths (null: every row holds uniform_ctx tokens)
+    int           uniform_ctx = 0;
 };
 
 namespace {
 
-int plan_reserve(nvk_plan *plan, size_t items, size_t seqs)
+int plan_reserve(nvk_plan *plan, size_t items, size_t seqs, hipStream_t stream)
 {
+    if (items > plan->cap_items || seqs > plan->cap_seqs) {
+        int rc = refuse_growth_under_capture(stream, "the decode plan");
+        if (rc != NVK_OK)
+            return rc;
+    }
     if (items > plan->cap_items) {
         if (plan->items) {
             HIP_TRY(hipDeviceSynchronize());
@@ -406,18 +471,29 @@ int build_plan(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, in
         plan->built = true;
         return NVK_OK;
     }
-    rc = plan_reserve(plan, (size_t)plan->item_bound, (size_t)num_seqs);
-    if (rc != NVK_OK)
-        return rc;
-    if (sh.max_chunks > 1) {
-        rc = ensure_workspace(pool, (size_t)num_seqs * sh.max_chunks * n_heads * pool->head_dim,
-                              (size_t)num_seqs * sh.max_chunks * n_heads * 2);
+    const int mods = flags & ~0xff;
+    plan->direct       = (mods & (NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN)) != 0;
+    plan->ctx_lens_dev = (mods & NVK_DECODE_UNIFORM) ? nullptr : ctx_dev;
+    plan->uniform_ctx  = max_ctx;
+    if (plan->direct && !(mods & NVK_DECODE_UNIFORM) && !ctx_dev)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "decode: NVK_DECODE_NO_PLAN needs the lengths on the device");
+    if (!plan->direct) {
+        rc = plan_reserve(plan, (size_t)plan->item_bound, (size_t)num_seqs, stream);
         if (rc != NVK_OK)
             return rc;
     }
-    hipLaunchKernelGGL(nvk::nvk_plan_kernel, dim3(1), dim3(nvk::kPlanThreads), 0, stream, ctx_dev, num_seqs,
-                       sh.chunk_tokens, sh.max_chunks, plan->items, plan->counters, plan->counters + 1);
-    HIP_TRY(hipGetLastError());
+    if (sh.max_chunks > 1) {
+        rc = ensure_workspace(pool, (size_t)num_seqs * sh.max_chunks * n_heads * pool->head_dim,
+                              (size_t)num_seqs * sh.max_chunks * n_heads * 2,
+                              sh.fuse_merge ? (size_t)num_seqs * sh.qgroups : 0, stream);
+        if (rc != NVK_OK)
+            return rc;
+    }
+    if (!plan->direct) {
+        hipLaunchKernelGGL(nvk::nvk_plan_kernel, dim3(1), dim3(nvk::kPlanThreads), 0, stream, ctx_dev, num_seqs,
+                           sh.chunk_tokens, sh.max_chunks, plan->items, plan->counters, plan->counters + 1);
+        HIP_TRY(hipGetLastError());
+    }
     plan->built = true;
     return NVK_OK;
 }
@@ -440,7 +516,8 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     const int kv_mul  = n_heads / pool->n_kv_heads;
     if (sh.max_chunks > 1
         && (pool->ws_o_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * pool->head_dim
-            || pool->ws_ml_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * 2))
+            || pool->ws_ml_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * 2
+            || (sh.fuse_merge && pool->arrivals_cap < (size_t)plan->num_seqs * sh.qgroups)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "decode: split-K workspace smaller than the plan needs");
 
     nvk::DecodeParams p;
@@ -466,6 +543,15 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     p.kv_waves     = sh.waves;
     p.merge_off    = sh.merge_off;
     p.q_scale      = 1.44269504088896340736f / sqrtf((float)pool->head_dim);
+    p.direct       = plan->direct ? 1 : 0;
+    p.num_seqs     = plan->num_seqs;
+    p.chunk_tokens = sh.chunk_tokens;
+    p.uniform_ctx  = plan->uniform_ctx;
+    p.ctx_lens     = plan->ctx_lens_dev;
+    p.arrivals     = sh.fuse_merge ? pool->arrivals : nullptr;
+#ifdef NVK_STAMPS
+    p.stamps = g_debug_stamps;
+#endif
 
     const int       qsplit = kv_mul / sh.qpk;
     const int       padded = qsplit > 1 ? round_up(plan->item_bound, 8) : plan->item_bound;
@@ -481,20 +567,25 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     if (ev_attn_end)
         HIP_TRY(hipEventRecord(ev_attn_end, stream));
 
-    if (sh.max_chunks > 1) {
-        // few rows cut into many chunks: one workgroup per (row, head), chunks side by side; otherwise a thread per
-        // output float4 walking its chunks (NVK_MERGE_WIDE_ROWS = 0 switches the first form off)
-        if (sh.max_chunks >= 4 && sh.max_chunks <= nvk::kMergeWideMaxChunks && n_heads <= 65535
+    if (sh.max_chunks > 1 && !sh.fuse_merge) {
+        // The combine as a kernel of its own.  Few rows cut into many chunks: one workgroup per (row, head), chunks
+        // side by side; otherwise a thread per output float4 walking its chunks (NVK_MERGE_WIDE_ROWS = 0 switches
+        // the first form off, NVK_DECODE_MERGE_SEPARATE asks for the second).  Without a plan the kernels work
+        // the chunk counts out of the lengths themselves.
+        const int *seq_chunks = plan->direct ? nullptr : plan->counters + 1;
+        if (!sh.force_serial_merge && sh.max_chunks >= 4 && sh.max_chunks <= nvk::kMergeWideMaxChunks && n_heads <= 65535
             && (long long)plan->num_seqs * n_heads <= NVK_MERGE_WIDE_ROWS) {
             const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)n_heads);
             hipLaunchKernelGGL(nvk::nvk_merge_wide_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
-                               plan->counters + 1, out_dev, n_heads, pool->head_dim, sh.max_chunks);
+                               seq_chunks, plan->ctx_lens_dev, plan->uniform_ctx, sh.chunk_tokens, out_dev, n_heads,
+                               pool->head_dim, sh.max_chunks);
         }
         else {
             const int  vecs = n_heads * (pool->head_dim / 4);
             const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)((vecs + 255) / 256));
-            hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
-                               plan->counters + 1, out_dev, n_heads, pool->head_dim, sh.max_chunks);
+            hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml, seq_chunks,
+                               plan->ctx_lens_dev, plan->uniform_ctx, sh.chunk_tokens, out_dev, n_heads, pool->head_dim,
+                               sh.max_chunks);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -933,6 +1024,8 @@ int nvk_pool_destroy(nvk_pool *pool)
         (void)hipFree(pool->ws_o);
     if (pool->ws_ml)
         (void)hipFree(pool->ws_ml);
+    if (pool->arrivals)
+        (void)hipFree(pool->arrivals);
     free_plan(pool->own_plan);
     if (pool->rope_inv_freq)
         (void)hipFree(pool->rope_inv_freq);
@@ -1284,12 +1377,20 @@ int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int ma
     rc             = own_plan_of(pool, &plan);
     if (rc != NVK_OK)
         return rc;
-    rc = plan_reserve(plan, (size_t)num_seqs * shape.max_chunks, (size_t)num_seqs);
+    rc = plan_reserve(plan, (size_t)num_seqs * shape.max_chunks, (size_t)num_seqs, nullptr);
     if (rc != NVK_OK)
         return rc;
     return ensure_workspace(pool, (size_t)num_seqs * shape.max_chunks * n_heads * pool->head_dim,
-                            (size_t)num_seqs * shape.max_chunks * n_heads * 2);
+                            (size_t)num_seqs * shape.max_chunks * n_heads * 2, (size_t)num_seqs * shape.qgroups, nullptr);
 }
+
+#ifdef NVK_STAMPS
+int nvk_debug_set_stamps(void *dev_buffer)
+{
+    g_debug_stamps = (unsigned long long *)dev_buffer;
+    return NVK_OK;
+}
+#endif
 
 int nvk_plan_create(nvk_pool *pool, nvk_plan **out_plan)
 {
@@ -1316,10 +1417,10 @@ int nvk_plan_destroy(nvk_plan *plan)
 int nvk_plan_build(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_lens_dev, int max_ctx, int flags,
                    int chunk_tokens, void *stream)
 {
-    if (!plan || num_seqs < 0 || max_ctx < 0 || (num_seqs > 0 && !ctx_lens_dev))
+    if (!plan || num_seqs < 0 || max_ctx < 0 || (num_seqs > 0 && !ctx_lens_dev && !(flags & NVK_DECODE_UNIFORM)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: bad arguments");
-    if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: flags %d", flags);
+    if (!decode_flags_ok(flags))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: flags 0x%x", flags);
     nvk::DeviceScope scope(plan->pool->device);
     return build_plan(plan, num_seqs, n_heads, ctx_lens_dev, max_ctx, flags, chunk_tokens,
                       stream ? (hipStream_t)stream : plan->pool->stream);
@@ -1355,10 +1456,10 @@ int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, cons
     if (rc != NVK_OK)
         return rc;
     if (num_seqs < 0 || max_blocks <= 0 || max_ctx < 0
-        || (num_seqs > 0 && (!q_dev || !block_tables_dev || !ctx_lens_dev || !out_dev)))
+        || (num_seqs > 0 && (!q_dev || !block_tables_dev || (!ctx_lens_dev && !(flags & NVK_DECODE_UNIFORM)) || !out_dev)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: bad arguments");
-    if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: flags %d", flags);
+    if (!decode_flags_ok(flags))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: flags 0x%x", flags);
     nvk::DeviceScope scope(pool->device);
     return enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
                           out_dev, flags, chunk_tokens, stream ? (hipStream_t)stream : pool->stream);
@@ -1372,8 +1473,8 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
         return rc;
     if (num_seqs < 0 || max_blocks <= 0 || (num_seqs > 0 && (!q || !block_tables || !ctx_lens || !out)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode: bad arguments");
-    if (flags != NVK_DECODE_AUTO && flags != NVK_DECODE_SINGLE_PASS && flags != NVK_DECODE_SPLIT_K)
-        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode: flags %d", flags);
+    if (!decode_flags_ok(flags))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode: flags 0x%x", flags);
     if (num_seqs == 0)
         return NVK_OK;
 
@@ -1395,6 +1496,10 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
         }
         max_ctx = std::max(max_ctx, ctx);
     }
+    // the plan modifiers speak about lengths the library cannot see; here it can: decide for the caller
+    flags &= ~(NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN);
+    if (std::all_of(ctx_lens, ctx_lens + num_seqs, [&](int c) { return c == max_ctx; }))
+        flags |= NVK_DECODE_UNIFORM; // every row holds max_ctx tokens: the plan's order is the direct order
 
     nvk::DeviceScope  scope(pool->device);
     const size_t q_b   = (size_t)num_seqs * n_heads * pool->head_dim * sizeof(float);
@@ -1439,7 +1544,8 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
     if (rc == NVK_OK)
         rc = ensure_pin(pool, in_bytes + q_a);
     if (rc == NVK_OK && sh.max_chunks > 1)
-        rc = ensure_workspace(pool, (size_t)bound * n_heads * pool->head_dim, (size_t)bound * n_heads * 2);
+        rc = ensure_workspace(pool, (size_t)bound * n_heads * pool->head_dim, (size_t)bound * n_heads * 2,
+                              sh.fuse_merge ? (size_t)num_seqs * sh.qgroups : 0, pool->stream);
     if (rc != NVK_OK)
         return rc;
     std::memcpy(pool->pin, q, q_b);
@@ -1530,7 +1636,8 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
     // One timed region: ev_a .. ev_b brackets all `iters` layer-calls (plan rebuilds included).
     // Inside it, when attn_ms is wanted, every kAttnSampleEvery-th attention-kernel launch has its
     // own event pair (an event pair costs the stream about 6 us, so not every launch carries one).
-    constexpr int           kAttnSampleEvery = 8;
+    // (every launch when the region is short: the driver's default run is 20 layer-calls)
+    const int               kAttnSampleEvery = iters <= 32 ? 1 : 8;
     const int               n_samples = attn_ms ? (iters + kAttnSampleEvery - 1) / kAttnSampleEvery : 0;
     std::vector<hipEvent_t> ev((size_t)2 * n_samples, nullptr);
     hipError_t              e = hipSuccess;
@@ -1685,7 +1792,7 @@ int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, con
             return rc;
         if (work.max_parts > 1) {
             rc = ensure_workspace(pool, (size_t)work.total_q * work.max_parts * n_heads * pool->head_dim,
-                                  (size_t)work.total_q * work.max_parts * n_heads * 2);
+                                  (size_t)work.total_q * work.max_parts * n_heads * 2, 0, st);
             if (rc != NVK_OK)
                 return rc;
         }
@@ -1713,7 +1820,7 @@ int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, con
             const int  vecs = n_heads * (pool->head_dim / 4);
             const dim3 mgrid((unsigned)work.total_q, (unsigned)((vecs + 255) / 256));
             hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, st, pool->ws_o, pool->ws_ml, work.row_parts_dev,
-                               out_dev, n_heads, pool->head_dim, work.max_parts);
+                               (const int *)nullptr, 0, 1, out_dev, n_heads, pool->head_dim, work.max_parts);
             HIP_TRY(hipGetLastError());
         }
         return NVK_OK;

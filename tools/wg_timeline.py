@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of one nvk_decode_kernel launch (diagnostic build with -DNVK_STAMPS only):
+    NVK_LIB_PATH=build/variants/stamps.so python tools/wg_timeline.py --workload config2 [--geom llama] [bench flags]
+Stamps (100 MHz): 0 entry, 1 table staged, 2 main loop done (wave 0), 3 partial stored, 4 workgroup met,
+5 arrival known, 6 combine done."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np  # noqa: E402
+
+import nano_vllm_amd as nv  # noqa: E402
+from bench import make_workload  # noqa: E402
+from hipmem import DeviceArray  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="config2")
+ap.add_argument("--geom", default="llama")
+ap.add_argument("--flags", type=lambda x: int(x, 0), default=0)
+ap.add_argument("--uniform", action="store_true")
+a = ap.parse_args()
+work = make_workload(a.workload, 0, a.geom)
+g = work.geom
+pool = nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim)
+pool.fill_uniform(0, 1, 2)
+q = work.q()
+qd, td, cd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(work.ctx_lens)
+out = DeviceArray(np.zeros_like(q))
+nwg = 1 << 16
+st = DeviceArray(np.zeros((nwg, 8), np.uint64))
+lib = nv._capi.lib
+flags = a.flags | (nv.UNIFORM if a.uniform else 0)
+for it in range(4):
+    lib.nvk_debug_set_stamps(C.c_void_p(st.data_ptr() if it == 3 else 0))
+    nv.decode_device(pool, 0, work.num_seqs, g.n_heads, qd, td, work.max_blocks, cd, work.max_ctx, out, flags, 0)
+    pool.synchronize()
+s = st.numpy().astype(np.int64)
+live = s[:, 0] > 0
+s = s[live]
+t0 = s[:, 0].min()
+us = lambda x: (x - t0) / 100.0
+print(f"{work.name}: {live.sum()} workgroups stamped")
+def dist(name, v):
+    v = np.sort(v)
+    print(f"  {name:34s} min {v[0]:8.2f}  p10 {v[len(v)//10]:8.2f}  med {v[len(v)//2]:8.2f}  p90 {v[(9*len(v))//10]:8.2f}  max {v[-1]:8.2f} us")
+dist("entry", us(s[:, 0]))
+ok = s[:, 1] > 0
+dist("table staged - entry", (s[ok, 1] - s[ok, 0]) / 100.0)
+ok = s[:, 2] > 0
+dist("main loop (2 - 1)", (s[ok, 2] - s[ok, 1]) / 100.0)
+dist("main loop end", us(s[ok, 2]))
+ok = s[:, 4] > 0
+if ok.any():
+    dist("store+drain+barrier (4 - 2)", (s[ok, 4] - s[ok, 2]) / 100.0)
+    dist("arrival known (5 - 4)", (s[ok, 5] - s[ok, 4]) / 100.0)
+    red = s[:, 6] > 0
+    dist("combine (6 - 5), reducers", (s[red, 6] - s[red, 5]) / 100.0)
+    dist("reducer end", us(s[red, 6]))
+last = np.maximum.reduce([s[:, i] for i in range(8)], axis=0)
+dist("workgroup end", us(last))
