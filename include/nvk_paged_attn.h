@@ -222,6 +222,21 @@ int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, cons
                       const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
                       float *out_dev, int flags, int chunk_tokens, void *stream);
 
+/* nvk_decode_device for callers that cannot allocate.  No counterpart in the reference (its attention function
+ * takes a caller-owned scratch array, include/core/attention.hpp:86, and owns nothing): this one is for callers
+ * that must not reach hipMalloc / hipFree -- a stream under hipGraph capture, a tight serving loop, a harness that
+ * forbids allocation.  Same arguments, same kernels and same results as nvk_decode_device; the work list, the
+ * split-K partials and the arrival counters live in a static device array of nvk_noalloc_scratch_bytes()
+ * (24 MiB, held on every GPU the library runs on until the process ends) instead of buffers grown on demand.
+ * A batch that needs more (rows x chunks x n_heads x (head_dim + 2) floats, plus the work list) is refused with
+ * NVK_ERR_INVALID_ARG and a message saying how much it needs.  Calls on one GPU share the array: two calls that
+ * overlap in time on one GPU (different streams, different threads, different pools) race; calls ordered on one
+ * stream, or separated by a wait, do not. */
+int nvk_decode_device_noalloc(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                              const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
+                              float *out_dev, int flags, int chunk_tokens, void *stream);
+size_t nvk_noalloc_scratch_bytes(void);
+
 /* Paged chunked-prefill attention: causal attention of each sequence's chunk of
  * new tokens over the paged pool.  Row (s, b) of out equals Attention::paged_attention
  * (include/core/attention.hpp:82-159) with num_tokens = chunk_starts[s] + b + 1 over table row s --

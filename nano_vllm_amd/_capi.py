@@ -97,6 +97,11 @@ SIGNATURES = {
         C.c_int,
         [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
     ),
+    "nvk_decode_device_noalloc": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
+    ),
+    "nvk_noalloc_scratch_bytes": (C.c_size_t, []),
     "nvk_decode_bench": (
         C.c_int,
         [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -126,6 +126,21 @@ def decode_device(pool: PagedKVPool, layer: int, num_seqs: int, n_heads: int, q_
                                             _devptr(stream)))
 
 
+def decode_device_noalloc(pool: PagedKVPool, layer: int, num_seqs: int, n_heads: int, q_dev, block_tables_dev,
+                          max_blocks: int, ctx_lens_dev, max_ctx: int, out_dev, flags: int = AUTO,
+                          chunk_tokens: int = 0, stream=None) -> None:
+    """:func:`decode_device` for callers that must not allocate: work list, split-K partials and arrival counters
+    live in the library's static device array (``noalloc_scratch_bytes()``); larger batches are refused."""
+    _capi.check(_capi.lib.nvk_decode_device_noalloc(pool.handle, int(layer), int(num_seqs), int(n_heads),
+                                                    _devptr(q_dev), _devptr(block_tables_dev), int(max_blocks),
+                                                    _devptr(ctx_lens_dev), int(max_ctx), _devptr(out_dev), int(flags),
+                                                    int(chunk_tokens), _devptr(stream)))
+
+
+def noalloc_scratch_bytes() -> int:
+    return int(_capi.lib.nvk_noalloc_scratch_bytes())
+
+
 class DecodePlan:
     """A batch's decode work list, reusable across the layers of one model step (``nvk_plan_*``)."""
 

@@ -12,6 +12,10 @@ namespace nvk {
 // Records `msg` (printf-style) as the calling thread's last error and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// This device's address of the static scratch array behind nvk_decode_device_noalloc (hipGetSymbolAddress, once per
+// device; the calling thread's current device must be `device`).
+int noalloc_scratch_on(int device, unsigned char **out);
+
 // ---- RoPE + KV append in the epilogue of the q / k / v GEMV (one or two rows) -----------------
 // Where nvk_rope_append_kernel would put a step's rows: the layer's slabs, the step's tables and positions, the
 // frequency table.  Filled by nvk_paged_attn.hip, consumed by nvk_linear.hip.

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -453,9 +454,8 @@ int plan_reserve(nvk_plan *plan, size_t items, size_t seqs, hipStream_t stream)
     return NVK_OK;
 }
 
-// Builds `plan` for a batch on `stream` (one small kernel).  ctx_dev is a device pointer.
-int build_plan(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, int max_ctx, int flags, int chunk_tokens,
-               hipStream_t stream)
+// The host half of a plan: launch shape and planning mode for a batch.  Touches no device memory.
+int plan_prepare(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, int max_ctx, int flags, int chunk_tokens)
 {
     nvk_pool *pool = plan->pool;
     plan->built    = false;
@@ -467,16 +467,42 @@ int build_plan(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, in
         return nvk::fail(NVK_ERR_INVALID_ARG, "num_seqs=%d x %d chunks exceeds the grid", num_seqs, sh.max_chunks);
     plan->num_seqs = num_seqs, plan->n_heads = n_heads, plan->max_ctx = max_ctx;
     plan->item_bound = num_seqs * sh.max_chunks;
-    if (num_seqs == 0) {
-        plan->built = true;
-        return NVK_OK;
-    }
     const int mods = flags & ~0xff;
     plan->direct       = (mods & (NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN)) != 0;
     plan->ctx_lens_dev = (mods & NVK_DECODE_UNIFORM) ? nullptr : ctx_dev;
     plan->uniform_ctx  = max_ctx;
-    if (plan->direct && !(mods & NVK_DECODE_UNIFORM) && !ctx_dev)
+    if (num_seqs > 0 && plan->direct && !(mods & NVK_DECODE_UNIFORM) && !ctx_dev)
         return nvk::fail(NVK_ERR_INVALID_ARG, "decode: NVK_DECODE_NO_PLAN needs the lengths on the device");
+    return NVK_OK;
+}
+
+// The device half: the work list, written into plan->items / plan->counters by one small kernel on `stream`
+// (nothing to do for a plan-free launch).
+int plan_launch(nvk_plan *plan, const int *ctx_dev, hipStream_t stream)
+{
+    if (!plan->direct && plan->num_seqs > 0) {
+        hipLaunchKernelGGL(nvk::nvk_plan_kernel, dim3(1), dim3(nvk::kPlanThreads), 0, stream, ctx_dev, plan->num_seqs,
+                           plan->shape.chunk_tokens, plan->shape.max_chunks, plan->items, plan->counters,
+                           plan->counters + 1);
+        HIP_TRY(hipGetLastError());
+    }
+    plan->built = true;
+    return NVK_OK;
+}
+
+// Builds `plan` for a batch on `stream`, growing the plan's and the pool's buffers where needed.
+int build_plan(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, int max_ctx, int flags, int chunk_tokens,
+               hipStream_t stream)
+{
+    nvk_pool *pool = plan->pool;
+    int       rc   = plan_prepare(plan, num_seqs, n_heads, ctx_dev, max_ctx, flags, chunk_tokens);
+    if (rc != NVK_OK)
+        return rc;
+    const LaunchShape &sh = plan->shape;
+    if (num_seqs == 0) {
+        plan->built = true;
+        return NVK_OK;
+    }
     if (!plan->direct) {
         rc = plan_reserve(plan, (size_t)plan->item_bound, (size_t)num_seqs, stream);
         if (rc != NVK_OK)
@@ -489,21 +515,34 @@ int build_plan(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_dev, in
         if (rc != NVK_OK)
             return rc;
     }
-    if (!plan->direct) {
-        hipLaunchKernelGGL(nvk::nvk_plan_kernel, dim3(1), dim3(nvk::kPlanThreads), 0, stream, ctx_dev, num_seqs,
-                           sh.chunk_tokens, sh.max_chunks, plan->items, plan->counters, plan->counters + 1);
-        HIP_TRY(hipGetLastError());
-    }
-    plan->built = true;
-    return NVK_OK;
+    return plan_launch(plan, ctx_dev, stream);
+}
+
+// Where a launch keeps what it needs besides its inputs and outputs: the split-K partials and the arrival
+// counters.  Normally the pool's own buffers (grown on demand); nvk_decode_device_noalloc brings slices of
+// the library's static device array instead.
+struct Workspace
+{
+    float *ws_o = nullptr, *ws_ml = nullptr;
+    int   *arrivals = nullptr;
+    size_t o_floats = 0, ml_floats = 0, arrival_ints = 0;
+};
+
+Workspace pool_workspace(const nvk_pool *pool)
+{
+    Workspace w;
+    w.ws_o = pool->ws_o, w.ws_ml = pool->ws_ml, w.arrivals = pool->arrivals;
+    w.o_floats = pool->ws_o_floats, w.ml_floats = pool->ws_ml_floats, w.arrival_ints = pool->arrivals_cap;
+    return w;
 }
 
 // Enqueue one layer-call of a built plan on `stream`.  All pointers are device pointers.
 // ev_attn_begin/ev_attn_end (optional) bracket the attention kernel alone.
 int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float *q_dev, const int *tables_dev,
                     int max_blocks, float *out_dev, hipStream_t stream, hipEvent_t ev_attn_begin,
-                    hipEvent_t ev_attn_end, const int *table_rows_dev = nullptr)
+                    hipEvent_t ev_attn_end, const int *table_rows_dev = nullptr, const Workspace *given = nullptr)
 {
+    const Workspace ws = given ? *given : pool_workspace(pool);
     if (!plan->built || plan->pool != pool)
         return nvk::fail(NVK_ERR_INVALID_ARG, "decode: the plan was not built for this pool");
     if (plan->num_seqs == 0)
@@ -515,9 +554,9 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     const int n_heads = plan->n_heads;
     const int kv_mul  = n_heads / pool->n_kv_heads;
     if (sh.max_chunks > 1
-        && (pool->ws_o_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * pool->head_dim
-            || pool->ws_ml_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * 2
-            || (sh.fuse_merge && pool->arrivals_cap < (size_t)plan->num_seqs * sh.qgroups)))
+        && (ws.o_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * pool->head_dim
+            || ws.ml_floats < (size_t)plan->num_seqs * sh.max_chunks * n_heads * 2
+            || (sh.fuse_merge && ws.arrival_ints < (size_t)plan->num_seqs * sh.qgroups)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "decode: split-K workspace smaller than the plan needs");
 
     nvk::DecodeParams p;
@@ -529,8 +568,8 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     p.items        = plan->items;
     p.n_items      = plan->counters;
     p.out          = out_dev;
-    p.ws_o         = pool->ws_o;
-    p.ws_ml        = pool->ws_ml;
+    p.ws_o         = ws.ws_o;
+    p.ws_ml        = ws.ws_ml;
     p.max_blocks   = max_blocks;
     p.num_blocks   = pool->num_blocks;
     p.block_size   = pool->block_size;
@@ -548,7 +587,7 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     p.chunk_tokens = sh.chunk_tokens;
     p.uniform_ctx  = plan->uniform_ctx;
     p.ctx_lens     = plan->ctx_lens_dev;
-    p.arrivals     = sh.fuse_merge ? pool->arrivals : nullptr;
+    p.arrivals     = sh.fuse_merge ? ws.arrivals : nullptr;
 #ifdef NVK_STAMPS
     p.stamps = g_debug_stamps;
 #endif
@@ -576,14 +615,14 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
         if (!sh.force_serial_merge && sh.max_chunks >= 4 && sh.max_chunks <= nvk::kMergeWideMaxChunks && n_heads <= 65535
             && (long long)plan->num_seqs * n_heads <= NVK_MERGE_WIDE_ROWS) {
             const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)n_heads);
-            hipLaunchKernelGGL(nvk::nvk_merge_wide_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml,
+            hipLaunchKernelGGL(nvk::nvk_merge_wide_kernel, mgrid, dim3(256), 0, stream, ws.ws_o, ws.ws_ml,
                                seq_chunks, plan->ctx_lens_dev, plan->uniform_ctx, sh.chunk_tokens, out_dev, n_heads,
                                pool->head_dim, sh.max_chunks);
         }
         else {
             const int  vecs = n_heads * (pool->head_dim / 4);
             const dim3 mgrid((unsigned)plan->num_seqs, (unsigned)((vecs + 255) / 256));
-            hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, pool->ws_o, pool->ws_ml, seq_chunks,
+            hipLaunchKernelGGL(nvk::nvk_merge_kernel, mgrid, dim3(256), 0, stream, ws.ws_o, ws.ws_ml, seq_chunks,
                                plan->ctx_lens_dev, plan->uniform_ctx, sh.chunk_tokens, out_dev, n_heads, pool->head_dim,
                                sh.max_chunks);
         }
@@ -987,6 +1026,16 @@ int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads
                                    "nvk_pool_create: %s (2 x %zu bytes requested)", hipGetErrorString(e), bytes);
         nvk_pool_destroy(pool);
         return code;
+    }
+    {
+        // set-up for nvk_decode_device_noalloc: this device's address of the static scratch array, resolved here,
+        // with the device current, so that entry point's own calls only look it up
+        unsigned char *unused = nullptr;
+        const int      rc     = nvk::noalloc_scratch_on(device, &unused);
+        if (rc != NVK_OK) {
+            nvk_pool_destroy(pool);
+            return rc;
+        }
     }
     if (head_dim % 2 == 0) {
         const int rc = ensure_rope_table(pool, 10000.0f); // config.rope_theta, include/core/model.hpp:40
@@ -1464,6 +1513,108 @@ int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, cons
     return enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
                           out_dev, flags, chunk_tokens, stream ? (hipStream_t)stream : pool->stream);
 }
+
+} // extern "C"
+
+// ---- the entry point that allocates nothing ------------------------------------------------------
+// nvk_decode_device for callers that cannot call hipMalloc (a stream under graph capture, a tight serving loop,
+// a harness that forbids it).  Everything nvk_decode_device would keep in buffers it allocates or grows -- the work
+// list, the split-K partials, the arrival counters -- lives in ONE array that is part of the code object, so it
+// exists on every GPU the library runs on from load to exit.  `nvk_noalloc_scratch` below is the host-side
+// stand-in for that array, NOT a device address: its address on a device comes from hipGetSymbolAddress with
+// that device current (each GPU holds its own copy), is resolved once per device and is what every use below goes
+// through.  Calls on one GPU share the array and its last contents: what must start at zero (the arrival
+// counters) is cleared on the stream at each call, and two calls that overlap in time on one GPU race.
+constexpr size_t kNoAllocScratchBytes = (size_t)24 << 20;
+static __device__ __align__(256) unsigned char nvk_noalloc_scratch[kNoAllocScratchBytes];
+
+namespace {
+constexpr int  kMaxDevices = 64;
+std::mutex     g_noalloc_mutex;
+unsigned char *g_noalloc_ptr[kMaxDevices] = {}; // per device: the array's address there
+} // namespace
+
+// The calling thread's current device must be `device`.
+int nvk::noalloc_scratch_on(int device, unsigned char **out)
+{
+    if (device < 0 || device >= kMaxDevices)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "device %d outside [0,%d)", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[device]) {
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(nvk_noalloc_scratch)));
+        if (!ptr)
+            return nvk::fail(NVK_ERR_HIP, "hipGetSymbolAddress gave a null address for the scratch array on device %d",
+                             device);
+        g_noalloc_ptr[device] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_noalloc_ptr[device];
+    return NVK_OK;
+}
+
+extern "C" size_t nvk_noalloc_scratch_bytes(void) { return kNoAllocScratchBytes; }
+
+extern "C" int nvk_decode_device_noalloc(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q_dev,
+                                         const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev,
+                                         int max_ctx, float *out_dev, int flags, int chunk_tokens, void *stream)
+{
+    int rc = check_pool_layer(pool, layer, "nvk_decode_device_noalloc");
+    if (rc != NVK_OK)
+        return rc;
+    if (num_seqs < 0 || max_blocks <= 0 || max_ctx < 0
+        || (num_seqs > 0 && (!q_dev || !block_tables_dev || (!ctx_lens_dev && !(flags & NVK_DECODE_UNIFORM)) || !out_dev)))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device_noalloc: bad arguments");
+    if (!decode_flags_ok(flags))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device_noalloc: flags 0x%x", flags);
+    if (num_seqs == 0)
+        return NVK_OK;
+    nvk::DeviceScope scope(pool->device);
+    if (!scope.ok)
+        return nvk::fail(NVK_ERR_HIP, "nvk_decode_device_noalloc: hipSetDevice(%d) failed", pool->device);
+    unsigned char *base = nullptr;
+    rc                  = nvk::noalloc_scratch_on(pool->device, &base);
+    if (rc != NVK_OK)
+        return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : pool->stream;
+
+    nvk_plan plan; // lives for this call; its device arrays are slices of the scratch array
+    plan.pool = pool;
+    rc        = plan_prepare(&plan, num_seqs, n_heads, ctx_lens_dev, max_ctx, flags, chunk_tokens);
+    if (rc != NVK_OK)
+        return rc;
+    const LaunchShape &sh = plan.shape;
+    // slices, each a multiple of 256 B: arrival counters | plan counters | plan items | (max, sum) | partial outputs
+    auto         al       = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t rows     = (size_t)num_seqs * sh.max_chunks;
+    const size_t arr_b    = sh.fuse_merge ? al((size_t)num_seqs * sh.qgroups * sizeof(int)) : 0;
+    const size_t cnt_b    = plan.direct ? 0 : al((size_t)(num_seqs + 1) * sizeof(int));
+    const size_t items_b  = plan.direct ? 0 : al(rows * sizeof(nvk::WorkItem));
+    const size_t ml_b     = sh.max_chunks > 1 ? al(rows * n_heads * 2 * sizeof(float)) : 0;
+    const size_t o_b      = sh.max_chunks > 1 ? al(rows * n_heads * pool->head_dim * sizeof(float)) : 0;
+    const size_t need     = arr_b + cnt_b + items_b + ml_b + o_b;
+    if (need > kNoAllocScratchBytes)
+        return nvk::fail(NVK_ERR_INVALID_ARG,
+                         "nvk_decode_device_noalloc: this batch needs %zu bytes of scratch (%d rows x %d chunks of %d "
+                         "tokens), the static array holds %zu: use fewer or longer chunks, or nvk_decode_device",
+                         need, num_seqs, sh.max_chunks, sh.chunk_tokens, kNoAllocScratchBytes);
+    Workspace ws;
+    ws.arrivals     = reinterpret_cast<int *>(base);
+    plan.counters   = reinterpret_cast<int *>(base + arr_b);
+    plan.items      = reinterpret_cast<nvk::WorkItem *>(base + arr_b + cnt_b);
+    ws.ws_ml        = reinterpret_cast<float *>(base + arr_b + cnt_b + items_b);
+    ws.ws_o         = reinterpret_cast<float *>(base + arr_b + cnt_b + items_b + ml_b);
+    ws.arrival_ints = arr_b / sizeof(int), ws.ml_floats = ml_b / sizeof(float), ws.o_floats = o_b / sizeof(float);
+    if (arr_b)
+        HIP_TRY(hipMemsetAsync(ws.arrivals, 0, arr_b, st)); // whatever the array's last user left there
+    rc = plan_launch(&plan, ctx_lens_dev, st);
+    if (rc == NVK_OK)
+        rc = enqueue_planned(pool, layer, &plan, q_dev, block_tables_dev, max_blocks, out_dev, st, nullptr, nullptr, nullptr,
+                             &ws);
+    plan.items = nullptr, plan.counters = nullptr; // not this plan's to free
+    return rc;
+}
+
+extern "C" {
 
 int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float *q, const int *block_tables,
                int max_blocks, const int *ctx_lens, float *out, int flags, int chunk_tokens)
