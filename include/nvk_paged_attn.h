@@ -52,6 +52,9 @@ extern "C" {
  * length that order is the natural one and the plan kernel is skipped: */
 #define NVK_DECODE_UNIFORM 0x400 /* every sequence holds exactly max_ctx tokens; ctx_lens_dev may be NULL   */
 #define NVK_DECODE_NO_PLAN 0x800 /* ragged lengths, read by the decode kernel itself; natural chunk order   */
+/* GQA groups of 5..16 q-heads over head_dim 64 / 128 run their dot products on fp32 MFMA tiles (exact fp32, another
+ * order of sums than the vector kernel).  This modifier keeps such a launch on the vector kernel (A/B, tests). */
+#define NVK_DECODE_VECTOR_ONLY 0x1000
 
 /* prefill flags */
 #define NVK_PREFILL_AUTO 0    /* library picks by chunk length                                      */

@@ -26,6 +26,7 @@ MERGE_IN_KERNEL = _capi.DECODE_MERGE_IN_KERNEL
 MERGE_SEPARATE = _capi.DECODE_MERGE_SEPARATE
 UNIFORM = _capi.DECODE_UNIFORM
 NO_PLAN = _capi.DECODE_NO_PLAN
+VECTOR_ONLY = _capi.DECODE_VECTOR_ONLY
 
 
 def bind_pool(pool: Optional[PagedKVPool], layer: int = 0) -> None:

@@ -58,7 +58,11 @@ static_assert(NVK_STEP_TOKENS % 4 == 0 && NVK_STEP_TOKENS >= 4, "a step is whole
 #ifndef NVK_TPL_VPL1
 #define NVK_TPL_VPL1 4 // tokens per lane per step for rows of <= 64 floats (twice the others: same bytes in flight)
 #endif
-constexpr int tok_per_lane(int vpl, int qpk) { return vpl == 1 ? NVK_TPL_VPL1 : NVK_STEP_TOKENS / 4; }
+// (one or two q-heads over rows of <= 64 floats leave registers for twice that again: 32-token steps, +7 %)
+constexpr int tok_per_lane(int vpl, int qpk)
+{
+    return vpl == 1 ? (qpk <= 2 ? 2 * NVK_TPL_VPL1 : NVK_TPL_VPL1) : NVK_STEP_TOKENS / 4;
+}
 constexpr int step_tokens(int vpl, int qpk) { return 4 * tok_per_lane(vpl, qpk); }
 // Waves per workgroup: 8 (two per SIMD, <= 256 VGPRs each) where q, the accumulators and two tiles fit 256
 // registers; 4 (one per SIMD, the whole register file: values the VALU is not working on sit in AGPRs) where
@@ -118,15 +122,19 @@ struct DecodeParams
     // between launches; the workgroup whose arrival completes a sequence's chunks merges them (null: the partials
     // are left for nvk_merge_kernel / nvk_merge_wide_kernel).
     int            *arrivals;
-#ifdef NVK_STAMPS // diagnostic build: eight 100 MHz timestamps per workgroup (tools/wg_timeline.py)
+#ifdef NVK_STAMPS // diagnostic build: sixteen 100 MHz timestamps per workgroup (tools/wg_timeline.py)
     unsigned long long *stamps;
 #endif
 };
 #ifdef NVK_STAMPS
 #define NVK_STAMP(i)                                                                                                   \
     if (p.stamps && threadIdx.x == 0)                                                                                  \
-        p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
+#define NVK_STAMP_WAVE()                                                                                               \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                                           \
+        p.stamps[(size_t)blockIdx.x * 16 + 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
 #else
+#define NVK_STAMP_WAVE()
 #define NVK_STAMP(i)
 #endif
 
@@ -161,15 +169,19 @@ template <int VPL, int TPL> struct KVTile
     float4 v[TPL][VPL];
 };
 
-__device__ __forceinline__ float4 load_kv(const float *p)
+// NT: the non-temporal hint, for row pieces made of whole 128-B lines (a read-once stream: +7-17 %).  A 192-B
+// piece (head_dim 48) shares a line with its neighbour kv-head, which another wave reads a little later: with
+// the hint that line is gone from L2 by then (measured: G-tiny 5b 0.65 -> 0.74 of peak without it).
+template <bool NT> __device__ __forceinline__ float4 load_kv(const float *p)
 {
 #if NVK_NT_LOADS
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
-#else
-    return *reinterpret_cast<const float4 *>(p);
+    if constexpr (NT) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
 #endif
+    return *reinterpret_cast<const float4 *>(p);
 }
 
 // ---- the plan kernel: context lengths -> work items, longest first ----------
@@ -317,6 +329,47 @@ __device__ __forceinline__ void merge_chunks(const float *ws_o, const float *ws_
         make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
+// ---- split-K combine by the workgroup that arrives last (cdna_hip_programming.md, Guideline 16) ----
+// Called by EVERY wave of a workgroup whose chunk's partial has just been stored write-through (sc1).  Every
+// storing wave drains its stores, the workgroup meets, ONE lane adds the arrival (agent scope).  Whoever draws
+// nch - 1 knows every chunk of the sequence has been written through: one agent-scope acquire (drops this CU's
+// stale lines), its wait, a barrier, then plain loads.  Nobody waits for anybody: no spin, no residency
+// assumption, any placement of the chunks over XCDs.  qpk = q-heads per kv-head wave of this launch.
+__device__ __forceinline__ void combine_if_last(const DecodeParams &p, int *s_flag, int seq, int nch, int kvg, int zq,
+                                                int qsplit, int qpk)
+{
+    NVK_STAMP(3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    NVK_STAMP(4)
+    const int qgroups = gridDim.x / p.items_padded; // (kv-head group, q sub-group) pairs = arrival counters per sequence
+    if (threadIdx.x == 0) {
+        int *cnt       = p.arrivals + (int64_t)seq * qgroups + (kvg * qsplit + zq);
+        const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == nch - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // zero again for the next launch
+        }
+        s_flag[0] = last; // (the table slice this word belonged to is dead: every wave is past its loop)
+    }
+    __syncthreads();
+    NVK_STAMP(5)
+    if (!s_flag[0])
+        return;
+    const int hd = p.head_dim, vec_row = hd >> 2;
+    const int n_mine = p.kv_waves * qpk * vec_row; // (q-head, float4) pairs of this workgroup's heads
+    for (int idx = threadIdx.x; idx < n_mine; idx += blockDim.x) {
+        const int hh = idx / vec_row, vec = idx - hh * vec_row;
+        const int w = hh / qpk, kvh_w = kvg * p.kv_waves + w;
+        if (kvh_w < p.n_kv_heads)
+            merge_chunks(p.ws_o, p.ws_ml, p.out, seq, kvh_w * p.kv_mul + zq * qpk + (hh - w * qpk), vec, nch, p.n_heads,
+                         hd, p.max_chunks);
+    }
+    NVK_STAMP(6)
+}
+
 // ---- the decode kernel ----------------------------------------------------
 // VPL   float4 per lane per row (head_dim <= 64*VPL)
 // QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.y also walks kv_mul/QPK)
@@ -445,22 +498,13 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
         return;
 
     // this wave's share of the chunk: whole steps
-    int w0 = t0, w1 = t1, stride = kStepTokens;
-    int nsteps = (t1 - t0 + kStepTokens - 1) / kStepTokens;
-    if (parts > 1) {
-#ifdef NVK_TOKEN_SPLIT_CONTIGUOUS // A/B build: each part takes one contiguous run of steps
-        const int per = (nsteps + parts - 1) / parts * kStepTokens;
-        w0            = min(t1, t0 + part * per);
-        w1            = min(t1, w0 + per);
-        nsteps        = (w1 - w0 + kStepTokens - 1) / kStepTokens;
-#else
-        // steps dealt round-robin: at any moment the workgroup's waves stream neighbouring rows, the access
-        // pattern of a workgroup whose waves are the kv-heads of one row
-        w0     = t0 + part * kStepTokens;
-        stride = parts * kStepTokens;
-        nsteps = nsteps > part ? (nsteps - part + parts - 1) / parts : 0;
-#endif
-    }
+    // (steps dealt round-robin over the token-split parts: at any moment the workgroup's waves stream neighbouring
+    // rows, the access pattern of a workgroup whose waves are the kv-heads of one row.  Of the two waves a SIMD
+    // hosts the one launched first streams 1.1-1.35 x faster -- profiles/r02_wave_timeline.log -- but dealing it
+    // more steps, 5:4 or 4:3, measured no gain: whoever finishes first leaves its bandwidth to the other.)
+    const int w1 = t1, w0 = t0 + part * kStepTokens, stride = parts * kStepTokens;
+    int       nsteps = (t1 - t0 + kStepTokens - 1) / kStepTokens;
+    nsteps           = nsteps > part ? (nsteps - part + parts - 1) / parts : 0;
     const bool has_tokens = live && nsteps > 0;
 
     // pre-scale q into the exp2 domain
@@ -502,7 +546,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
             for (int j = 0; j < VPL; j++) {
                 T.k[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act[j])
-                    T.k[i][j] = load_kv(p.k_layer + at[i] + 64 * j);
+                    T.k[i][j] = load_kv<FULL>(p.k_layer + at[i] + 64 * j);
             }
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++)
@@ -510,7 +554,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
             for (int j = 0; j < VPL; j++) {
                 T.v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act[j])
-                    T.v[i][j] = load_kv(p.v_layer + at[i] + 64 * j);
+                    T.v[i][j] = load_kv<FULL>(p.v_layer + at[i] + 64 * j);
             }
     };
 
@@ -591,6 +635,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
     }
 
     NVK_STAMP(2)
+    NVK_STAMP_WAVE()
     // merge the four token slots of the wave (lanes 16 and 32 apart)
 #pragma unroll
     for (int h = 0; h < QPK; h++) {
@@ -710,41 +755,322 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
     if (!fused)
         return;
 
-    // ---- split-K combine by the workgroup that arrives last (cdna_hip_programming.md, Guideline 16) ----
-    // Every storing wave drains its write-through stores, the workgroup meets, ONE lane adds the arrival
-    // (agent scope).  Whoever draws nch - 1 knows every chunk of the sequence has been written through:
-    // one agent-scope acquire (drops this CU's stale lines), its wait, a barrier, then plain loads.  Nobody
-    // waits for anybody: no spin, no residency assumption, any placement of the chunks over XCDs.
-    NVK_STAMP(3)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    combine_if_last(p, s_tab, seq, nch, kvg, zq, qsplit, QPK);
+}
+
+// ---- the decode kernel on fp32 MFMA tiles, for GQA groups of 5..16 q-heads --------------------------------
+// With many q-heads per kv-head the vector kernel above stops being a stream: at 8 q-heads over 64-float rows
+// it issues ~500 VALU instructions per 16 tokens per wave (8 x the dot products, 8 x the 16-lane DPP sums, the
+// exponentials 16 x redundantly), the two waves of a SIMD contend for issue slots and the younger one runs 1.6 x
+// slower (profiles/r02_wave_timeline.log): contraction-bound, which is where north_star asks for the matrix
+// cores.  Same work items, same block-table staging, same split-K / token-split / combine as nvk_decode_kernel;
+// only the inner products change:
+//   * a step is a tile of 16 tokens.  S[token][head] = K . Q^T on v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf
+//     chain): A = K with the token on lane & 15 and four dims per lane quarter (lane >> 4), B = the wave's Q
+//     fragment (head on lane & 15, heads past kv_mul zero), resident in HD / 4 registers.  HD / 4 MFMAs.
+//   * the result has the head on lane & 15 and tokens 4 * (lane >> 4) + reg in four registers -- which is exactly
+//     the B operand of O^T[dim][head] += V^T[dim][token] . P[token][head] with V in its natural coalesced
+//     layout (token 4 * (lane >> 4) + reg, dims 4 * (lane & 15) + c [+ 64]): no transpose, no LDS.  HD / 4 MFMAs.
+//   * softmax statistics per head = per lane column: 3 in-lane max + 2 exchanges (lanes 16 and 32 apart), FOUR
+//     exponentials per lane per tile; the running sum stays per lane and is joined once at the end.
+// K is loaded as 16 token rows x 64-B pieces per instruction (the A operand's shape), V as 4 rows x 256 B.
+// Bound: HBM; the MFMA pipe is ~35 % busy (32 or 64 MFMAs of 32 cycles per 16 tokens per wave, two waves per SIMD).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int HD> struct MfmaTile
+{
+    float4 k[HD / 16];
+    float4 v[4][HD / 64];
+};
+
+template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kernel(const DecodeParams p)
+{
+    constexpr int NM = HD / 16, NV = HD / 64, kStepTokens = 16, kRec = 4 + HD;
+    using Tile = MfmaTile<HD>;
+    extern __shared__ __attribute__((aligned(16))) int s_tab[];
+
+    NVK_STAMP(0)
+    const int kvg    = blockIdx.x / p.items_padded; // one wave carries the whole GQA group: no q sub-groups
+    const int item_i = blockIdx.x - kvg * p.items_padded;
+    int seq, chunk, nch = 0, t0, t1 = 0, ctx_raw = 0;
+    if (p.direct) {
+        if (item_i >= p.num_seqs * p.max_chunks)
+            return;
+        seq     = item_i / p.max_chunks;
+        chunk   = item_i - seq * p.max_chunks;
+        t0      = chunk * p.chunk_tokens;
+        ctx_raw = p.ctx_lens ? p.ctx_lens[seq] : p.uniform_ctx;
+    }
+    else {
+        if (item_i >= *p.n_items)
+            return;
+        const WorkItem item = p.items[item_i];
+        seq = item.seq, chunk = item.w & 0xFFFF, nch = item.w >> 16, t0 = item.t0, t1 = item.t1;
+    }
+    seq = __builtin_amdgcn_readfirstlane(seq), chunk = __builtin_amdgcn_readfirstlane(chunk);
+    t0  = __builtin_amdgcn_readfirstlane(t0);
+
+    const int  lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int  c16 = lane & 15, q4 = lane >> 4;
+    const int  parts = nwaves / p.kv_waves, part = wave / p.kv_waves;
+    const int  kvh  = kvg * p.kv_waves + wave % p.kv_waves;
+    const bool live = kvh < p.n_kv_heads;
+    const int  kv_mul = p.kv_mul;
+    const bool head_live = live && c16 < kv_mul; // lanes whose column is a real q-head
+    const int64_t head_row = (int64_t)seq * p.n_heads + kvh * kv_mul + c16; // row of q / out
+
+    // Q fragment: Q[head c16][dims 16 m + 4 q4 .. + 3]
+    float4 qf[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        qf[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (head_live)
+            qf[m] = *reinterpret_cast<const float4 *>(p.q + head_row * HD + 16 * m + 4 * q4);
+    }
+
+    const int blk0 = token_block(t0, p.bs_magic);
+    const int blk_last = p.direct ? min(token_block(t0 + p.chunk_tokens - 1, p.bs_magic), p.max_blocks - 1)
+                                  : (t1 > t0 ? token_block(t1 - 1, p.bs_magic) : blk0 - 1);
+    const int trow = p.table_rows ? p.table_rows[seq] : seq;
+    for (int i = threadIdx.x; i <= blk_last - blk0; i += blockDim.x)
+        s_tab[i] = clamp_block(p.block_tables[(int64_t)trow * p.max_blocks + blk0 + i], p.num_blocks);
+    if (p.direct) {
+        const int ctx = min(max(ctx_raw, 0), p.max_chunks * p.chunk_tokens);
+        nch           = (ctx + p.chunk_tokens - 1) / p.chunk_tokens;
+        t1            = min(ctx, t0 + p.chunk_tokens);
+        if (chunk >= max(nch, 1))
+            return;
+    }
+    nch = __builtin_amdgcn_readfirstlane(nch), t1 = __builtin_amdgcn_readfirstlane(t1);
     __syncthreads();
-    NVK_STAMP(4)
-    const int qgroups = gridDim.x / p.items_padded; // (kv-head group, q sub-group) pairs = arrival counters per sequence
-    if (threadIdx.x == 0) {
-        int *cnt       = p.arrivals + (int64_t)seq * qgroups + (kvg * qsplit + zq);
-        const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == nch - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // zero again for the next launch
+    NVK_STAMP(1)
+
+    if (t1 <= t0) { // no context: the reference zeroes `out` and does nothing else (attention.hpp:98)
+        if (head_live && part == 0) {
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+                *reinterpret_cast<float4 *>(p.out + head_row * HD + 16 * m + 4 * q4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        s_tab[0] = last; // the table slice is dead: every wave is past its loop
-    }
-    __syncthreads();
-    NVK_STAMP(5)
-    if (!s_tab[0])
         return;
-    const int vec_row = hd >> 2;
-    const int n_mine  = p.kv_waves * QPK * vec_row; // (q-head, float4) pairs of this workgroup's heads
-    for (int idx = threadIdx.x; idx < n_mine; idx += blockDim.x) {
-        const int hh = idx / vec_row, vec = idx - hh * vec_row;
-        const int w = hh / QPK, kvh_w = kvg * p.kv_waves + w;
-        if (kvh_w < p.n_kv_heads)
-            merge_chunks(p.ws_o, p.ws_ml, p.out, seq, kvh_w * p.kv_mul + zq * QPK + (hh - w * QPK), vec, nch, p.n_heads,
-                         hd, p.max_chunks);
     }
-    NVK_STAMP(6)
+    const bool fused = p.arrivals != nullptr && nch > 1;
+    if (!live && !fused)
+        return;
+
+    // (steps dealt round-robin over the token-split parts: at any moment the workgroup's waves stream neighbouring
+    // rows, the access pattern of a workgroup whose waves are the kv-heads of one row.  Of the two waves a SIMD
+    // hosts the one launched first streams 1.1-1.35 x faster -- profiles/r02_wave_timeline.log -- but dealing it
+    // more steps, 5:4 or 4:3, measured no gain: whoever finishes first leaves its bandwidth to the other.)
+    const int w1 = t1, w0 = t0 + part * kStepTokens, stride = parts * kStepTokens;
+    int       nsteps = (t1 - t0 + kStepTokens - 1) / kStepTokens;
+    nsteps           = nsteps > part ? (nsteps - part + parts - 1) / parts : 0;
+    const bool has_tokens = live && nsteps > 0;
+
+#pragma unroll
+    for (int m = 0; m < NM; m++)
+        qf[m].x *= p.q_scale, qf[m].y *= p.q_scale, qf[m].z *= p.q_scale, qf[m].w *= p.q_scale;
+
+    float m_run = kNegBig, l_run = 0.f; // this lane's head: running max (shared by its four lanes), this lane's share of the sum
+    f32x4 oacc[NV][4];                  // O[head c16][dims 64 j + 16 q4 + 4 reg + c] = oacc[j][c][reg]
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            oacc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row_len = p.n_kv_heads * HD;
+    auto row_at = [&](int tok) -> int64_t {
+        const int blk = token_block(tok, p.bs_magic);
+        const int off = token_offset(tok, blk, p.block_size);
+        return ((int64_t)s_tab[blk - blk0] * p.block_size + off) * row_len + kvh * HD;
+    };
+    auto load_tile = [&](Tile &T, int ts) {
+        // lanes past the chunk's end (last step only) re-read its last row; consume_tile masks their scores
+        const int64_t atk = row_at(min(ts + c16, w1 - 1)) + 4 * q4;
+        int64_t       atv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            atv[i] = row_at(min(ts + 4 * q4 + i, w1 - 1)) + 4 * c16;
+#ifdef NVK_MFMA_K_AS_V // TIMING ONLY (wrong results): K fetched in V's shape, 4 rows x 256 B per instruction
+#pragma unroll
+        for (int m = 0; m < NM; m++)
+            T.k[m] = load_kv<true>(p.k_layer + atv[m & 3] + 64 * (m >> 2));
+#else
+#pragma unroll
+        for (int m = 0; m < NM; m++)
+            T.k[m] = load_kv<true>(p.k_layer + atk + 16 * m);
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+                T.v[i][j] = load_kv<true>(p.v_layer + atv[i] + 64 * j);
+    };
+    auto consume_tile = [&](const Tile &T, int ts, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f}; // two chains: the pipe never waits on one
+#pragma unroll
+        for (int m = 0; m < NM; m += 2) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m].x, qf[m].x, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m + 1].x, qf[m + 1].x, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m].y, qf[m].y, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m + 1].y, qf[m + 1].y, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m].z, qf[m].z, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m + 1].z, qf[m + 1].z, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m].w, qf[m].w, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(T.k[m + 1].w, qf[m + 1].w, s1, 0, 0, 0);
+        }
+        float s[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            s[r] = s0[r] + s1[r]; // token ts + 4 q4 + r, head c16
+            if (TAIL && ts + 4 * q4 + r >= w1)
+                s[r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        mx       = fmaxf(mx, __shfl_xor(mx, 16));
+        mx       = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn    = fmaxf(m_run, mx);
+        const float alpha = fast_exp2(m_run - mn);
+        float       pw[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            pw[r] = fast_exp2(s[r] - mn);
+        m_run = mn;
+        l_run = fmaf(l_run, alpha, (pw[0] + pw[1]) + (pw[2] + pw[3]));
+        // the running max settles after the first tiles: skip the rescale whenever no head saw a new maximum
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    oacc[j][c] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                oacc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(T.v[r][j].x, pw[r], oacc[j][0], 0, 0, 0);
+                oacc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(T.v[r][j].y, pw[r], oacc[j][1], 0, 0, 0);
+                oacc[j][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(T.v[r][j].z, pw[r], oacc[j][2], 0, 0, 0);
+                oacc[j][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(T.v[r][j].w, pw[r], oacc[j][3], 0, 0, 0);
+            }
+    };
+
+    const std::integral_constant<bool, false> body;
+    const std::integral_constant<bool, true>  tail;
+    if (has_tokens) {
+        Tile ta, tb;
+        int  k = 0;
+        load_tile(ta, w0);
+        for (; k + 2 < nsteps; k += 2) {
+            load_tile(tb, w0 + (k + 1) * stride);
+            consume_tile(ta, w0 + k * stride, body);
+            load_tile(ta, w0 + (k + 2) * stride);
+            consume_tile(tb, w0 + (k + 1) * stride, body);
+        }
+        if (nsteps - k == 2) {
+            load_tile(tb, w0 + (k + 1) * stride);
+            consume_tile(ta, w0 + k * stride, body);
+            consume_tile(tb, w0 + (k + 1) * stride, tail);
+        }
+        else {
+            consume_tile(ta, w0 + k * stride, tail);
+        }
+    }
+    NVK_STAMP(2)
+    NVK_STAMP_WAVE()
+
+    // the four lanes of a head (16 and 32 apart) join their shares of the sum; the max is already common
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+
+    // token-split: the parts of one kv-head meet in LDS, record = (m, l, -, -, o[HD]) per (wave, head)
+    if (parts > 1) {
+        float *s_mrg = reinterpret_cast<float *>(s_tab + p.merge_off);
+        if (part > 0 && head_live) {
+            float *rec = s_mrg + (wave * kv_mul + c16) * kRec;
+            if (q4 == 0)
+                rec[0] = m_run, rec[1] = l_run;
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    *reinterpret_cast<float4 *>(rec + 4 + 64 * j + 16 * q4 + 4 * r) =
+                        make_float4(oacc[j][0][r], oacc[j][1][r], oacc[j][2][r], oacc[j][3][r]);
+        }
+        __syncthreads();
+        if (part > 0 && !fused)
+            return;
+        if (part == 0 && head_live) {
+            float mw = m_run;
+            for (int q = 1; q < parts; q++)
+                mw = fmaxf(mw, s_mrg[((q * p.kv_waves + wave) * kv_mul + c16) * kRec]);
+            const float f0 = fast_exp2(m_run - mw);
+            float       lw = l_run * f0;
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    oacc[j][c] *= f0;
+            for (int q = 1; q < parts; q++) {
+                const float *rec = s_mrg + ((q * p.kv_waves + wave) * kv_mul + c16) * kRec;
+                const float  f   = fast_exp2(rec[0] - mw);
+                lw               = fmaf(rec[1], f, lw);
+#pragma unroll
+                for (int j = 0; j < NV; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float4 b = *reinterpret_cast<const float4 *>(rec + 4 + 64 * j + 16 * q4 + 4 * r);
+                        oacc[j][0][r]  = fmaf(b.x, f, oacc[j][0][r]);
+                        oacc[j][1][r]  = fmaf(b.y, f, oacc[j][1][r]);
+                        oacc[j][2][r]  = fmaf(b.z, f, oacc[j][2][r]);
+                        oacc[j][3][r]  = fmaf(b.w, f, oacc[j][3][r]);
+                    }
+            }
+            m_run = mw, l_run = lw;
+        }
+    }
+
+    const bool writer = head_live && part == 0;
+    if (nch == 1) {
+        if (!writer)
+            return;
+        const float mf  = fmaxf(m_run, kRefMaxFloorLog2); // the reference's max_val = -1e10 floor (attention.hpp:126-130)
+        const float f   = fast_exp2(m_run - mf);
+        const float inv = f / (l_run * f);
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                *reinterpret_cast<float4 *>(p.out + head_row * HD + 64 * j + 16 * q4 + 4 * r) =
+                    make_float4(oacc[j][0][r] * inv, oacc[j][1][r] * inv, oacc[j][2][r] * inv, oacc[j][3][r] * inv);
+        return;
+    }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int kSc1 = 16;
+    if (writer) { // the chunk's unnormalised partial, write-through (see nvk_decode_kernel)
+        const int64_t slab = (int64_t)seq * p.max_chunks + chunk;
+        const __amdgpu_buffer_rsrc_t rs_o =
+            __builtin_amdgcn_make_buffer_rsrc(p.ws_o + slab * p.n_heads * HD, 0, p.n_heads * HD * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_ml =
+            __builtin_amdgcn_make_buffer_rsrc(p.ws_ml + slab * p.n_heads * 2, 0, p.n_heads * 8, 0x00020000);
+        const int head = kvh * kv_mul + c16;
+#pragma unroll
+        for (int j = 0; j < NV; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(u32x4, make_float4(oacc[j][0][r], oacc[j][1][r], oacc[j][2][r], oacc[j][3][r])),
+                    rs_o, (head * HD + 64 * j + 16 * q4 + 4 * r) * 4, 0, kSc1);
+        if (q4 == 0)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(m_run, l_run)), rs_ml, head * 8, 0,
+                                                  kSc1);
+    }
+    if (!fused)
+        return;
+    combine_if_last(p, s_tab, seq, nch, kvg, 0, 1, kv_mul);
 }
 
 // ---- split-K merge (flash-decoding combine) ---------------------------------

@@ -40,6 +40,9 @@
 #ifndef NVK_AUTO_MAX_CHUNK
 #define NVK_AUTO_MAX_CHUNK 2048 // longest chunk NVK_DECODE_AUTO picks
 #endif
+#ifndef NVK_MFMA_MIN_KVMUL
+#define NVK_MFMA_MIN_KVMUL 5 // q-heads per kv-head from which decode runs on fp32 MFMA tiles (head_dim 64 or 128, <= 16 heads)
+#endif
 #ifndef NVK_FUSE_MAX_CHUNKS
 #define NVK_FUSE_MAX_CHUNKS 16 // chunks per sequence up to which the split-K combine runs inside the decode kernel (the
                                // workgroup that completes a sequence merges it: one CU's worth of reading, fine for a
@@ -245,7 +248,7 @@ int check_pool_layer(const nvk_pool *pool, int layer, const char *who)
 }
 
 #ifdef NVK_STAMPS
-unsigned long long *g_debug_stamps = nullptr; // diagnostic build only: [workgroups, 8] device buffer
+unsigned long long *g_debug_stamps = nullptr; // diagnostic build only: [workgroups, 16] device buffer
 #endif
 
 // ------------------------------------------------------------ launch plan
@@ -260,6 +263,7 @@ struct LaunchShape
     int qpk          = 1; // q-heads per wave
     int vpl          = 1;
     bool full        = false;
+    bool mfma        = false; // nvk_decode_mfma_kernel: one wave carries the whole GQA group on 16-token MFMA tiles
     size_t lds_bytes = 0;
     int  qgroups     = 1;     // (kv-head group, q sub-group) pairs per item = arrival counters per row
     bool fuse_merge  = false; // max_chunks > 1: the decode kernel combines a row's chunks itself
@@ -272,7 +276,8 @@ bool decode_flags_ok(int flags)
     const int mode = flags & 0xff, mods = flags & ~0xff;
     if (mode != NVK_DECODE_AUTO && mode != NVK_DECODE_SINGLE_PASS && mode != NVK_DECODE_SPLIT_K)
         return false;
-    if (mods & ~(NVK_DECODE_MERGE_IN_KERNEL | NVK_DECODE_MERGE_SEPARATE | NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN))
+    if (mods & ~(NVK_DECODE_MERGE_IN_KERNEL | NVK_DECODE_MERGE_SEPARATE | NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN
+                 | NVK_DECODE_VECTOR_ONLY))
         return false;
     return !((mods & NVK_DECODE_MERGE_IN_KERNEL) && (mods & NVK_DECODE_MERGE_SEPARATE));
 }
@@ -302,14 +307,18 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
             plan->qpk = d;
             break;
         }
-    const int wg_waves = std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl, plan->qpk, plan->full));
+    plan->mfma = plan->full && (hd == 64 || hd == 128) && kv_mul >= NVK_MFMA_MIN_KVMUL && kv_mul <= 16
+                 && !(mods & NVK_DECODE_VECTOR_ONLY);
+    if (plan->mfma)
+        plan->qpk = kv_mul;
+    const int wg_waves = plan->mfma ? 8 : std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl, plan->qpk, plan->full));
     plan->waves      = std::min(pool->n_kv_heads, wg_waves);
     plan->kv_groups  = (pool->n_kv_heads + plan->waves - 1) / plan->waves;
     // fewer kv-heads than a workgroup has waves (a head-sharded rank, a small model): the other waves split
     // the chunk's tokens, so the workgroup still has all its waves' loads in flight
     plan->parts      = plan->kv_groups == 1 ? std::max(1, wg_waves / plan->waves) : 1;
 
-    const int step    = nvk::step_tokens(plan->vpl, plan->qpk);
+    const int step    = plan->mfma ? 16 : nvk::step_tokens(plan->vpl, plan->qpk);
     const int ctx_cap = round_up(std::max(max_ctx, 1), step);
     // a workgroup stages its chunk's table slice in LDS: bound the chunk by that
     const long long slice_cap = (long long)kMaxTableSliceEntries * pool->block_size / step * step;
@@ -392,6 +401,13 @@ template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, d
 
 hipError_t launch_decode(const LaunchShape &plan, dim3 grid, dim3 block, hipStream_t stream, const nvk::DecodeParams &p)
 {
+    if (plan.mfma) {
+        if (plan.vpl == 1)
+            hipLaunchKernelGGL((nvk::nvk_decode_mfma_kernel<64>), grid, block, plan.lds_bytes, stream, p);
+        else
+            hipLaunchKernelGGL((nvk::nvk_decode_mfma_kernel<128>), grid, block, plan.lds_bytes, stream, p);
+        return hipGetLastError();
+    }
     switch (plan.vpl) {
     case 1: return launch_decode_qpk<1>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
     case 2: return launch_decode_qpk<2>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);

@@ -30,7 +30,7 @@ q = work.q()
 qd, td, cd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(work.ctx_lens)
 out = DeviceArray(np.zeros_like(q))
 nwg = 1 << 16
-st = DeviceArray(np.zeros((nwg, 8), np.uint64))
+st = DeviceArray(np.zeros((nwg, 16), np.uint64))
 lib = nv._capi.lib
 flags = a.flags | (nv.UNIFORM if a.uniform else 0)
 for it in range(4):
@@ -59,5 +59,11 @@ if ok.any():
     red = s[:, 6] > 0
     dist("combine (6 - 5), reducers", (s[red, 6] - s[red, 5]) / 100.0)
     dist("reducer end", us(s[red, 6]))
-last = np.maximum.reduce([s[:, i] for i in range(8)], axis=0)
+last = np.maximum.reduce([s[:, i] for i in range(16)], axis=0)
 dist("workgroup end", us(last))
+print("  per-wave main-loop time (wave end - table staged), median over workgroups:")
+for w in range(8):
+    ok = s[:, 8 + w] > 0
+    if ok.any():
+        d = np.sort((s[ok, 8 + w] - s[ok, 1]) / 100.0)
+        print(f"    wave {w}: min {d[0]:8.2f}  med {d[len(d)//2]:8.2f}  max {d[-1]:8.2f} us")
