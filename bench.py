@@ -74,10 +74,11 @@ def make_workload(name, rank=0, geom="llama"):
     raise SystemExit(f"unknown workload {name}")
 
 
-def profiled_traffic(work_name, kernel="nvk::nvk_decode_kernel<2, 4, true>"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile of this same
-    workload (profiles/r*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950
-    corrections applied as MI355X_MICROARCH.md prescribes).  None when no profile matches."""
+def profiled_traffic(work_name, kernel):
+    """HBM bytes per launch of `kernel` (the instantiation this run launched, as rocprofv3 names it) from the
+    committed PMC profile of this same workload (profiles/r*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 corrections applied as MI355X_MICROARCH.md prescribes).  The latest round wins; None when no
+    profile holds this (workload, kernel) pair -- never a number measured on another kernel."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
@@ -170,6 +171,46 @@ def cpu_baseline(work, cores):
     return one, many
 
 
+def extra_workloads(nv, torch, dev, args):
+    """The other BASELINE.json configs on one GPU, a few steps each (they are parity-test cases first; these
+    lines make their rates visible to whoever runs the default bench): {name: {ms_per_step, GBps, frac, ...}}."""
+    res = {}
+    for name in ("config3", "config4", "5a", "5b"):
+        work = make_workload(name)
+        g = work.geom
+        uniform_batch = bool((work.ctx_lens == work.ctx_lens[0]).all())
+        flags = nv.AUTO | (nv.UNIFORM if uniform_batch else 0)
+        with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=dev.index) as pool:
+            pool.fill_uniform(0, 1, 2)
+            q = torch.from_numpy(work.q()).to(dev)
+            tabs = torch.from_numpy(work.block_tables).to(dev)
+            ctx = torch.from_numpy(work.ctx_lens).to(dev)
+            out = torch.empty_like(q)
+            torch.cuda.synchronize()
+            kname = nv.decode_kernel_name(pool, work.num_seqs, g.n_heads, work.max_ctx, flags, 0)
+
+            def run(warmup, iters, want_attn):
+                return nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
+                                       out, flags, 0, warmup, iters, replan_every=1, want_attn=want_attn)
+
+            steps = 10
+            run(3, 0, False)
+            step_ms, _ = run(0, steps, False)
+            _, attn_ms = run(0, steps, True)
+            nbytes = work.algorithmic_bytes()
+            res[name] = {"workload": work.name, "steps": steps, "ms_per_step": round(step_ms, 4),
+                         "GBps": round(nbytes / (step_ms * 1e-3) / 1e9, 1),
+                         "frac": round(nbytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "kernel": kname, "kernel_ms": round(attn_ms, 4),
+                         "kernel_frac": round(nbytes / (attn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "traffic": profiled_traffic(work.name, kname), "algorithmic_bytes": nbytes,
+                         "plan": "none: uniform lengths" if uniform_batch else "nvk_plan_kernel every layer-call",
+                         "tokens_per_s": round(work.num_seqs / (step_ms * 1e-3), 1)}
+        del q, tabs, ctx, out
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +239,14 @@ def main():
                     help="torch.distributed backend for N>1: nccl (= RCCL, the real one) or gloo (rehearsal of the "
                          "multi-process path on a box with fewer GPUs than ranks; ranks then share GPUs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="N=1 only: also time the batch over this many different KV slabs in turn (cold rotation, "
+                         "SURVEY.md 8d) and report it beside the resident number; 1 = off")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed launches of the same step for about this long before the W warm-up steps, so that the "
+                         "clocks have reached their steady state when the timed region starts (0 = off)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="N=1 only: skip the extra BASELINE configs (3, 4, 5a, 5b) timed after the headline workload")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no per-kernel event pairs inside the timed region (roofline from step time)")
     args = ap.parse_args()
@@ -259,30 +308,48 @@ def main():
         g = wl.Geometry(hs.local_heads, hs.local_kv_heads, g.head_dim, g.block_size)
         work = wl.Workload(work.name + f"_heads{rank}of{world}", g, work.num_blocks, work.ctx_lens, work.block_tables,
                            work.fragmented)
-    pool = nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=local_rank)
-    pool.fill_uniform(0, 1 + 16 * rank, 2 + 16 * rank)
+    rotate = max(1, args.rotate) if (args.shard == "seq" and world == 1) else 1
+    pool = nv.PagedKVPool(rotate, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=local_rank)
+    for layer in range(rotate):
+        pool.fill_uniform(layer, 1 + 16 * rank + 2 * layer, 2 + 16 * rank + 2 * layer)
     q = torch.from_numpy(work.q()).to(dev)
     tabs = torch.from_numpy(work.block_tables).to(dev)
     ctx = torch.from_numpy(work.ctx_lens).to(dev)
     out = torch.empty_like(q)
     torch.cuda.synchronize()
+    kernel_name = nv.decode_kernel_name(pool, work.num_seqs, g.n_heads, work.max_ctx, flags, args.chunk)
 
-    def run(warmup, iters):
+    def run(warmup, iters, want_attn, layers=1):
         return nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
-                               flags, args.chunk, warmup, iters, replan_every=args.replan,
-                               want_attn=not args.no_kernel_events)
+                               flags, args.chunk, warmup, iters, replan_every=args.replan, want_attn=want_attn,
+                               rotate_layers=layers)
 
+    rotated = None
     if args.shard == "seq":
-        run(args.warmup, 0)  # W untimed steps (also sizes the split-K workspace)
+        if args.prewarm_ms > 0:  # (sizes the split-K workspace too)
+            t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+            while time.perf_counter() < t_end:
+                run(20, 0, False)
+        run(args.warmup, 0, False)  # W untimed steps
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
-        step_ms, attn_ms = run(0, args.steps)  # EXACTLY K steps; HIP events on the launch stream inside
-        if attn_ms is None:
-            attn_ms = step_ms
+        step_ms, _ = run(0, args.steps, False)  # EXACTLY K steps, nothing but the path's own launches on the stream
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         barrier()
+        # the dominant kernel's own duration: the same K launches again, each between a pair of HIP events on the
+        # launch stream (a pair costs the stream ~6 us, which is why it is not inside the region `value` comes from)
+        if args.no_kernel_events:
+            attn_ms = step_ms
+        else:
+            _, attn_ms = run(0, args.steps, True)
+        if rotate > 1:  # the same batch over `rotate` different slabs in turn: nothing can be served from the Infinity Cache
+            run(rotate, 0, False, rotate)
+            r_step, _ = run(0, args.steps, False, rotate)
+            _, r_attn = run(0, args.steps, True, rotate)
+            rotated = (r_step, r_attn)
+        torch.cuda.synchronize()
     else:
         # attention on torch's current stream, then the all-gather on the same stream: K x (decode + gather)
         # (an explicit side stream: the C ABI reads a NULL stream as "the pool's own stream", and torch's
@@ -315,7 +382,7 @@ def main():
         wall = time.perf_counter() - t0
         barrier()
         step_ms = ev0.elapsed_time(ev1) / args.steps
-        _, attn_ms = run(2, 16)  # the attention kernel alone in this rank's shape, HIP events on the pool's stream
+        _, attn_ms = run(2, 16, True)  # the attention kernel alone in this rank's shape, HIP events on the pool's stream
         torch.cuda.synchronize()
 
     if world > 1:
@@ -348,18 +415,32 @@ def main():
             "config": {"workload": work.name, "num_seqs_per_gpu": work.num_seqs, "total_ctx_tokens_per_gpu":
                        work.total_tokens, "n_heads": g.n_heads, "n_kv_heads": g.n_kv_heads, "head_dim": g.head_dim,
                        "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode, "replan_every": args.replan, "plan": planning,
-                       "merge": args.merge,
+                       "merge": args.merge, "prewarm_ms": args.prewarm_ms,
                        "parallelism": (f"sequence-sharded x{world}, no collective" if args.shard == "seq" else
                                        f"head-sharded x{world}, one RCCL all-gather of out per layer-call")},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
             "tokens_per_s": round(seqs_all / (ms_per_step * 1e-3), 1),
             "tokens_per_s_32_layer_model": round(seqs_all / (ms_per_step * 1e-3) / 32.0, 1),
             "event_ms_per_step": round(step_ms, 4),
-            "roofline": {"bound": "hbm", "kernel": "nvk_decode_kernel", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": profiled_traffic(work.name) if args.mode == "auto" and args.chunk == 0 else None,
-                         "kernel_ms": round(attn_ms, 4), "algorithmic_bytes": nbytes},
+                         "traffic": profiled_traffic(work.name, kernel_name) if args.mode == "auto" and args.chunk == 0
+                         else None,
+                         "kernel_ms": round(attn_ms, 4), "algorithmic_bytes": nbytes,
+                         "kernel_events": ("none: step time" if args.no_kernel_events else
+                                           f"HIP event pair around each of {args.steps} launches on the launch stream, "
+                                           "a second pass right after the timed region")},
         }
+        if rotated is not None:
+            r_step, r_attn = rotated
+            line["rotated"] = {"slabs": rotate, "slab_bytes": int(2 * 4 * work.num_blocks * g.block_size * g.n_kv_heads * g.head_dim),
+                               "ms_per_step": round(r_step, 4), "GBps": round(nbytes / (r_step * 1e-3) / 1e9, 1),
+                               "kernel_ms": round(r_attn, 4),
+                               "kernel_frac": round(nbytes / (r_attn * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        if world == 1 and args.shard == "seq" and not args.no_extra and args.workload == "config2" and args.geom == "llama":
+            pool.close()
+            pool = None
+            line["workloads"] = extra_workloads(nv, torch, dev, args)
         if world == 1 and not args.no_cpu:
             cores = min(16, os.cpu_count() or 1)
             one, many = cpu_baseline(work, cores)
@@ -369,7 +450,8 @@ def main():
                 line["cpu_baseline_all_cores"] = many
         print(json.dumps(line), flush=True)
 
-    pool.close()
+    if pool is not None:
+        pool.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -296,6 +296,17 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
                      float *out_dev, int flags, int chunk_tokens, int replan_every, int warmup, int iters,
                      float *total_ms, float *attn_ms);
 
+/* The same with call i reading layer first_layer + i % n_rotate of the pool (identical batches over n_rotate
+ * different slabs): no call can find its K/V in the 256 MiB Infinity Cache left there by the call before. */
+int nvk_decode_bench_layers(nvk_pool *pool, int first_layer, int n_rotate, int num_seqs, int n_heads,
+                            const float *q_dev, const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev,
+                            int max_ctx, float *out_dev, int flags, int chunk_tokens, int replan_every, int warmup,
+                            int iters, float *total_ms, float *attn_ms);
+/* Name of the attention kernel instantiation a launch of this shape runs (as rocprofv3 prints it), for matching
+ * profiles to launches. */
+int nvk_decode_kernel_name(nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens,
+                           char *buf, int cap);
+
 /* Drop-in for the reference function, same eleven arguments, host pointers.
  * ref: Attention::paged_attention, include/core/attention.hpp:82-92.
  *  - With a pool bound on this thread (nvk_bind_pool), key_cache/value_cache

@@ -108,6 +108,12 @@ SIGNATURES = {
         [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
          C.c_int, _f, _f],
     ),
+    "nvk_decode_bench_layers": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.c_int, _f, _f],
+    ),
+    "nvk_decode_kernel_name": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nvk_plan_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "nvk_plan_destroy": (C.c_int, [_vp]),
     "nvk_plan_build": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),

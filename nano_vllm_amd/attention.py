@@ -177,13 +177,24 @@ class DecodePlan:
 def decode_bench(pool: PagedKVPool, layer: int, num_seqs: int, n_heads: int, q_dev, block_tables_dev,
                  max_blocks: int, ctx_lens_dev, max_ctx: int, out_dev, flags: int = AUTO, chunk_tokens: int = 0,
                  warmup: int = 5, iters: int = 20, want_attn: bool = True,
-                 replan_every: int = 1) -> Tuple[float, Optional[float]]:
-    """HIP-event timing on the pool's stream: (ms per layer-call, ms per attention kernel)."""
+                 replan_every: int = 1, rotate_layers: int = 1) -> Tuple[float, Optional[float]]:
+    """HIP-event timing on the pool's stream: (ms per layer-call, ms per attention kernel).  With rotate_layers > 1
+    call i reads layer ``layer + i % rotate_layers`` (cold rotation over several slabs)."""
     total = C.c_float(0.0)
     attn = C.c_float(0.0)
-    _capi.check(_capi.lib.nvk_decode_bench(pool.handle, int(layer), int(num_seqs), int(n_heads), _devptr(q_dev),
-                                           _devptr(block_tables_dev), int(max_blocks), _devptr(ctx_lens_dev),
-                                           int(max_ctx), _devptr(out_dev), int(flags), int(chunk_tokens),
-                                           int(replan_every), int(warmup), int(iters), C.byref(total),
-                                           C.byref(attn) if want_attn else None))
+    _capi.check(_capi.lib.nvk_decode_bench_layers(pool.handle, int(layer), int(rotate_layers), int(num_seqs),
+                                                  int(n_heads), _devptr(q_dev), _devptr(block_tables_dev),
+                                                  int(max_blocks), _devptr(ctx_lens_dev), int(max_ctx),
+                                                  _devptr(out_dev), int(flags), int(chunk_tokens), int(replan_every),
+                                                  int(warmup), int(iters), C.byref(total),
+                                                  C.byref(attn) if want_attn else None))
     return float(total.value), (float(attn.value) if want_attn else None)
+
+
+def decode_kernel_name(pool: PagedKVPool, num_seqs: int, n_heads: int, max_ctx: int, flags: int = AUTO,
+                       chunk_tokens: int = 0) -> str:
+    """The attention kernel instantiation a launch of this shape runs, as rocprofv3 names it."""
+    buf = C.create_string_buffer(128)
+    _capi.check(_capi.lib.nvk_decode_kernel_name(pool.handle, int(num_seqs), int(n_heads), int(max_ctx), int(flags),
+                                                 int(chunk_tokens), buf, 128))
+    return buf.value.decode()

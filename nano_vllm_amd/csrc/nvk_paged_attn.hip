@@ -1765,9 +1765,37 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
                      int flags, int chunk_tokens, int replan_every, int warmup, int iters, float *total_ms,
                      float *attn_ms)
 {
-    int rc = check_pool_layer(pool, layer, "nvk_decode_bench");
+    return nvk_decode_bench_layers(pool, layer, 1, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev,
+                                   max_ctx, out_dev, flags, chunk_tokens, replan_every, warmup, iters, total_ms, attn_ms);
+}
+
+int nvk_decode_kernel_name(nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens, char *buf,
+                           int cap)
+{
+    if (!pool || !buf || cap <= 0 || !decode_flags_ok(flags))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_kernel_name: bad arguments");
+    LaunchShape sh;
+    int         rc = make_shape(pool, num_seqs, n_heads, max_ctx, flags, chunk_tokens, &sh);
     if (rc != NVK_OK)
         return rc;
+    if (sh.mfma)
+        snprintf(buf, (size_t)cap, "nvk::nvk_decode_mfma_kernel<%d>", 64 * sh.vpl);
+    else
+        snprintf(buf, (size_t)cap, "nvk::nvk_decode_kernel<%d, %d, %s>", sh.vpl, sh.qpk, sh.full ? "true" : "false");
+    return NVK_OK;
+}
+
+int nvk_decode_bench_layers(nvk_pool *pool, int first_layer, int n_rotate, int num_seqs, int n_heads, const float *q_dev,
+                            const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
+                            float *out_dev, int flags, int chunk_tokens, int replan_every, int warmup, int iters,
+                            float *total_ms, float *attn_ms)
+{
+    int rc = check_pool_layer(pool, first_layer, "nvk_decode_bench");
+    if (rc != NVK_OK)
+        return rc;
+    if (n_rotate < 1 || first_layer + n_rotate > pool->n_layers)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_bench: layers [%d, %d) outside the pool's %d", first_layer,
+                         first_layer + n_rotate, pool->n_layers);
     if (iters < 0 || warmup < 0 || num_seqs <= 0 || iters > 100000 || replan_every < 1)
         return nvk::fail(NVK_ERR_INVALID_ARG,
                          "nvk_decode_bench: need 0 <= iters <= 100000, warmup >= 0, num_seqs > 0, replan_every >= 1");
@@ -1785,7 +1813,10 @@ int nvk_decode_bench(nvk_pool *pool, int layer, int num_seqs, int n_heads, const
             if (r != NVK_OK)
                 return r;
         }
-        return enqueue_planned(pool, layer, plan, q_dev, block_tables_dev, max_blocks, out_dev, st, a, b);
+        // call i reads layer first_layer + i % n_rotate: with n_rotate slabs larger together than the 256 MiB
+        // Infinity Cache no call finds any of its bytes there
+        return enqueue_planned(pool, first_layer + i % n_rotate, plan, q_dev, block_tables_dev, max_blocks, out_dev, st, a,
+                               b);
     };
     for (int i = 0; i < warmup; i++) {
         rc = one_call(i, nullptr, nullptr);
