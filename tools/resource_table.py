@@ -20,7 +20,7 @@ for line in open(sys.argv[1]):
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 names = [r["name"] for r in rows]
 try:
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
 except OSError:
     dem = names
 print(f"{'kernel':58s} {'VGPR':>4s} {'AGPR':>4s} {'SGPR':>4s} {'spillV':>6s} {'scratch B/lane':>14s} {'LDS B':>6s} {'waves/SIMD':>10s}")
