@@ -351,32 +351,52 @@ def main():
             rotated = (r_step, r_attn)
         torch.cuda.synchronize()
     else:
-        # attention on torch's current stream, then the all-gather on the same stream: K x (decode + gather)
-        # (an explicit side stream: the C ABI reads a NULL stream as "the pool's own stream", and torch's
-        # default stream IS the NULL stream, which would leave the gather unordered with the kernels)
-        gathered = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev)
+        # K x (attention of this rank's heads, then ONE all-gather of out).  With RCCL the gather goes through the
+        # library's own C ABI (nvk_shard_*: ncclAllGather called directly, on a communication stream behind an event)
+        # and is overlapped: layer-call i's gather runs under layer-call i + 1's attention, two (out, gathered)
+        # buffer pairs in turn, the consumer of gathered[i] waiting one step behind -- as the wo projection of a
+        # model's layer would.  With gloo (rehearsal: ranks share a GPU, which RCCL refuses) the collective runs on
+        # host copies through torch.distributed, not overlapped.
         side = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(side)
         stream = side.cuda_stream
-        assert stream != 0
+        assert stream != 0  # (the C ABI reads a NULL stream as "the pool's own stream")
+        outs = [out, torch.empty_like(out)]
+        gath = [torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev) for _ in range(2)]
+        shard = None
+        if args.backend == "nccl":
+            ids = [sh.NvkShard.new_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            shard = sh.NvkShard(rank, world, ids[0], local_rank, hs.n_heads, hs.n_kv_heads)
 
-        def step():
-            nv.decode_device(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
-                             flags, args.chunk, stream=stream)
-            if args.backend == "nccl":
-                hs.all_gather_out(out, gathered)
-            else:  # gloo rehearsal: the collective runs on host copies
-                gathered.copy_(hs.all_gather_out(out.cpu()))
+        def step(i):
+            b = i % 2
+            if shard is not None:
+                shard.decode_gather(pool, 0, work.num_seqs, q, tabs, work.max_blocks, ctx, work.max_ctx, outs[b],
+                                    gath[b], b, flags, args.chunk, compute_stream=stream)
+                if i > 0:
+                    shard.wait_gather(1 - b, stream)  # the consumer of the previous layer-call's rows
+            else:
+                nv.decode_device(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
+                                 outs[b], flags, args.chunk, stream=stream)
+                gath[b].copy_(hs.all_gather_out(outs[b].cpu()))
 
-        for _ in range(args.warmup):
-            step()
+        def drain(i):
+            if shard is not None and i > 0:
+                shard.wait_gather((i - 1) % 2, stream)
+
+        for i in range(args.warmup):
+            step(i)
+        drain(args.warmup)
         torch.cuda.synchronize()
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            step(i)
+        drain(args.steps)
         ev1.record()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
@@ -384,6 +404,8 @@ def main():
         step_ms = ev0.elapsed_time(ev1) / args.steps
         _, attn_ms = run(2, 16, True)  # the attention kernel alone in this rank's shape, HIP events on the pool's stream
         torch.cuda.synchronize()
+        if shard is not None:
+            shard.close()
 
     if world > 1:
         t = torch.tensor([wall, step_ms, attn_ms], dtype=torch.float64, device=red_dev)
@@ -417,7 +439,9 @@ def main():
                        "block_size": g.block_size, "fragmented_tables": work.fragmented, "mode": args.mode, "replan_every": args.replan, "plan": planning,
                        "merge": args.merge, "prewarm_ms": args.prewarm_ms,
                        "parallelism": (f"sequence-sharded x{world}, no collective" if args.shard == "seq" else
-                                       f"head-sharded x{world}, one RCCL all-gather of out per layer-call")},
+                                       f"head-sharded x{world}, one all-gather of out per layer-call ("
+                                       + ("RCCL via nvk_shard_*, overlapped with the next layer-call" if args.backend == "nccl"
+                                          else "gloo on host copies: rehearsal") + ")")},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
             "tokens_per_s": round(seqs_all / (ms_per_step * 1e-3), 1),
             "tokens_per_s_32_layer_model": round(seqs_all / (ms_per_step * 1e-3) / 32.0, 1),

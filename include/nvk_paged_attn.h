@@ -347,6 +347,42 @@ long long nvk_host_cache_staged_bytes(int reset);
  * ref: the layer slicing in LlamaModel::attention, include/core/model.hpp:400-403. */
 int nvk_bind_pool(nvk_pool *pool, int layer);
 
+/* ------------------------------------------------------- head-sharded decode --
+ * The decode layer-call split over the G GPUs of one node by kv-head group.  The reference has one
+ * process and no collective; heads are independent in it (q-head loop outermost, include/core/attention.hpp:102,
+ * kv-head h / kv_mul, :105), so rank g holds kv-heads [g*KV/G, (g+1)*KV/G) of every sequence in its own pool of
+ * [num_blocks, block_size, KV/G, head_dim] (same block tables on every rank), computes its q-heads' slice of out,
+ * and ONE all-gather per layer-call joins the slices: gathered [G, num_seqs, H/G, head_dim], transpose-free.
+ * The collective is RCCL's ncclAllGather over xGMI, called directly (librccl.so is opened by the first of these
+ * calls).  One process per GPU: rank 0 asks nvk_shard_unique_id for 128 bytes and hands them to the other ranks by
+ * whatever channel the engine has, then every rank calls nvk_shard_create (collective: returns when all have).
+ * The sequence-sharded split needs none of this: its ranks share nothing.
+ *   nvk_shard_head_range    out4 = {local q-heads, local kv-heads, first q-head, first kv-head}; host only
+ *   nvk_shard_gather_bytes  bytes one rank contributes to the gather (x G = what it ends up holding); host only
+ *   nvk_shard_info          out6 = {rank, world, local q-heads, local kv-heads, first q-head, first kv-head}
+ *   nvk_shard_all_gather_out  the collective alone, on `stream` (NULL: the shard's own communication stream)
+ *   nvk_shard_decode_gather   nvk_decode_device on `compute_stream` (NULL: the pool's), then the gather on the
+ *       shard's communication stream behind an event: it runs under whatever `compute_stream` does next (the next
+ *       layer-call's attention).  `buffer` (0 or 1) names which of two (out_local, gathered) buffer pairs the call
+ *       uses; a pair is reused only after its gather has finished (the call orders that itself).
+ *   nvk_shard_wait_gather     makes `stream` (NULL: the calling thread) wait until buffer's gather has landed --
+ *       before the consumer of `gathered` (the wo projection, include/core/model.hpp:224) reads it. */
+typedef struct nvk_shard nvk_shard;
+int       nvk_shard_head_range(int rank, int world, int n_heads, int n_kv_heads, int *out4);
+long long nvk_shard_gather_bytes(int num_seqs, int n_heads, int head_dim, int world);
+int       nvk_shard_unique_id(void *id128);
+int       nvk_shard_create(int rank, int world, const void *id128, int device, int n_heads, int n_kv_heads,
+                           nvk_shard **out_shard);
+int       nvk_shard_destroy(nvk_shard *shard);
+int       nvk_shard_info(const nvk_shard *shard, int *out6);
+int       nvk_shard_all_gather_out(nvk_shard *shard, const float *out_local_dev, float *gathered_dev, int num_seqs,
+                                   int head_dim, void *stream);
+int       nvk_shard_decode_gather(nvk_shard *shard, nvk_pool *pool, int layer, int num_seqs, const float *q_local_dev,
+                                  const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
+                                  float *out_local_dev, float *gathered_dev, int buffer, int flags, int chunk_tokens,
+                                  void *compute_stream);
+int       nvk_shard_wait_gather(nvk_shard *shard, int buffer, void *stream);
+
 /* ------------------------------------------------------------ decode batch --
  * Per-request block tables kept on the device, and one append + attention call
  * per layer for all DECODING requests.

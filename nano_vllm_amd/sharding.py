@@ -14,9 +14,11 @@ tokens over its spare waves):
   all-gather per layer-call (:class:`HeadShard`; RCCL over xGMI on the GPUs,
   gloo in the CPU tests).
 
-One process per GPU, ``torch.distributed`` for the collective.  The attention
-itself is whatever callable the caller passes (``nano_vllm_amd.decode_device`` in
-``bench.py``); this module is host logic only and runs without a GPU.
+One process per GPU.  The collective has two carriers: ``torch.distributed``
+(:meth:`HeadShard.all_gather_out`; gloo in the CPU tests) and the library's own
+C ABI, ``nvk_shard_*`` (:class:`NvkShard`: RCCL called directly, the gather on a
+stream of its own under the next layer-call's attention) -- what a C++ engine uses.
+The partitioning helpers are host logic only and run without a GPU.
 """
 from __future__ import annotations
 
@@ -135,6 +137,85 @@ class HeadShard:
         dist.all_gather_into_tensor(gathered.view((-1,) + tuple(out_local.shape[1:])), out_local.contiguous(),
                                     group=group)
         return gathered
+
+
+def c_head_range(rank: int, world: int, n_heads: int, n_kv_heads: int) -> Tuple[int, int, int, int]:
+    """(local q-heads, local kv-heads, first q-head, first kv-head) from the C ABI's ``nvk_shard_head_range``
+    (host only; raises ValueError where :class:`HeadShard` would)."""
+    import ctypes as C
+
+    from . import _capi
+
+    out = (C.c_int * 4)()
+    if _capi.lib.nvk_shard_head_range(int(rank), int(world), int(n_heads), int(n_kv_heads), out) != 0:
+        raise ValueError(_capi.lib.nvk_last_error().decode())
+    return tuple(out)
+
+
+class NvkShard:
+    """One rank of the head-sharded split over the C ABI (``nvk_shard_*``, RCCL called directly).
+
+    ``unique_id`` is the 128-byte id rank 0 got from :meth:`new_unique_id`, handed to the other ranks by any
+    channel (``bench.py`` broadcasts it with torch.distributed).  Creation is collective."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes, device: int, n_heads: int, n_kv_heads: int):
+        import ctypes as C
+
+        from . import _capi
+
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of nvk_shard_unique_id")
+        self._capi, self._C = _capi, C
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        h = C.c_void_p()
+        _capi.check(_capi.lib.nvk_shard_create(int(rank), int(world), buf, int(device), int(n_heads), int(n_kv_heads),
+                                               C.byref(h)))
+        self._h = h
+        self.rank, self.world, self.n_heads, self.n_kv_heads = rank, world, n_heads, n_kv_heads
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _capi
+
+        buf = C.create_string_buffer(128)
+        _capi.check(_capi.lib.nvk_shard_unique_id(buf))
+        return buf.raw
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._capi.lib.nvk_shard_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def info(self) -> dict:
+        out = (self._C.c_int * 6)()
+        self._capi.check(self._capi.lib.nvk_shard_info(self._h, out))
+        return dict(zip(("rank", "world", "local_heads", "local_kv_heads", "first_head", "first_kv_head"), out))
+
+    def all_gather_out(self, out_local_dev, gathered_dev, num_seqs: int, head_dim: int, stream=None) -> None:
+        from .kv_pool import _devptr
+
+        self._capi.check(self._capi.lib.nvk_shard_all_gather_out(self._h, _devptr(out_local_dev), _devptr(gathered_dev),
+                                                                 int(num_seqs), int(head_dim), _devptr(stream)))
+
+    def decode_gather(self, pool, layer: int, num_seqs: int, q_local_dev, block_tables_dev, max_blocks: int,
+                      ctx_lens_dev, max_ctx: int, out_local_dev, gathered_dev, buffer: int, flags: int = 0,
+                      chunk_tokens: int = 0, compute_stream=None) -> None:
+        """Attention of this rank's heads on ``compute_stream``, then the all-gather on the shard's own stream."""
+        from .kv_pool import _devptr
+
+        self._capi.check(self._capi.lib.nvk_shard_decode_gather(
+            self._h, pool.handle, int(layer), int(num_seqs), _devptr(q_local_dev), _devptr(block_tables_dev),
+            int(max_blocks), _devptr(ctx_lens_dev), int(max_ctx), _devptr(out_local_dev), _devptr(gathered_dev),
+            int(buffer), int(flags), int(chunk_tokens), _devptr(compute_stream)))
+
+    def wait_gather(self, buffer: int, stream=None) -> None:
+        from .kv_pool import _devptr
+
+        self._capi.check(self._capi.lib.nvk_shard_wait_gather(self._h, int(buffer), _devptr(stream)))
 
 
 def assemble_heads(gathered):

@@ -22,7 +22,7 @@ def make_case():
     return work, g, k, v, tabs, c
 
 
-def run_rank(rank, world, port, result_path):
+def run_rank(rank, world, port, result_path, c_abi_ranges=False):
     import torch
     import torch.distributed as dist
 
@@ -50,6 +50,10 @@ def run_rank(rank, world, port, result_path):
         # ---- head-sharded: one all-gather of out per layer-call
         hs = sh.HeadShard(rank, world, g.n_heads, g.n_kv_heads)
         lo, hi = hs.kv_range
+        if c_abi_ranges:  # the slicing a C++ engine would do from nvk_shard_head_range
+            lh, lkv, h0, kv0 = sh.c_head_range(rank, world, g.n_heads, g.n_kv_heads)
+            assert (kv0, kv0 + lkv) == (lo, hi) and (h0, h0 + lh) == hs.q_range
+            lo, hi = kv0, kv0 + lkv
         k_loc = np.ascontiguousarray(k[:, :, lo:hi])
         v_loc = np.ascontiguousarray(v[:, :, lo:hi])
         out_loc = ol.oracle_decode_batch(hs.local_q(q), k_loc, v_loc, tabs, ctx, g.block_size, hs.local_kv_heads)

@@ -31,6 +31,33 @@ def test_two_ranks_over_gloo():
     assert text.startswith("[1, 1, 1]"), text
 
 
+def test_four_ranks_over_gloo_with_the_c_abi_head_ranges():
+    """world_size 4: both partitions reproduce the one-rank result bit for bit; the head ranges come from the
+    C ABI (nvk_shard_head_range) and must be HeadShard's."""
+    import torch.multiprocessing as mp
+
+    import shard_worker
+
+    with tempfile.TemporaryDirectory() as tmp:
+        result = os.path.join(tmp, "result.txt")
+        mp.spawn(shard_worker.run_rank, args=(4, _free_port(), result, True), nprocs=4, join=True)
+        text = open(result).read()
+    assert text.startswith("[1, 1, 1]"), text
+
+
+def test_c_abi_head_ranges_match_the_mirror():
+    for world, H, KV in ((1, 32, 8), (2, 32, 8), (4, 32, 8), (8, 32, 8), (4, 8, 4), (3, 24, 6), (2, 6, 6)):
+        for rank in range(world):
+            hs = sh.HeadShard(rank, world, H, KV)
+            assert sh.c_head_range(rank, world, H, KV) == (hs.local_heads, hs.local_kv_heads, hs.q_range[0], hs.kv_range[0])
+    for bad in ((0, 3, 32, 8), (2, 2, 32, 8), (0, 0, 32, 8), (0, 2, 30, 8)):
+        with pytest.raises(ValueError):
+            sh.c_head_range(*bad)
+    from nano_vllm_amd import _capi
+    assert _capi.lib.nvk_shard_gather_bytes(4096, 32, 128, 8) == 8 * 2 ** 20  # SURVEY.md 8e: 8 MiB per rank
+    assert _capi.lib.nvk_shard_gather_bytes(64, 32, 128, 8) == 128 * 2 ** 10
+
+
 def test_partition_sequences_balances_tokens_and_is_a_partition():
     from nano_vllm_amd import workloads as wl
 
