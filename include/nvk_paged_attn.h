@@ -487,7 +487,7 @@ int nvk_model_use_graphs(nvk_model *model, int on);
  * the GEMVs instead of running them as kernels: the wo / w_down GEMVs add their product to the residual stream and
  * leave x * gain and partial sums of squares, the GEMV that follows multiplies its product by 1 / rms (6 launches per
  * layer instead of 8).  1 / rms after the dot product instead of before it: a few ulp from the separate norm, inside
- * the tolerance; everything else keeps its bits.  On by default; 0 = the norms as kernels. */
+ * the tolerance; everything else keeps its bits.  OFF by default (the bits of the separate norm kernels); 1 opts in. */
 int nvk_model_use_linked_norms(nvk_model *model, int on);
 /* One model step: request i takes the next chunk_lens[i] >= 1 tokens of `tokens` (packed in list order; a prompt
  * chunk, or 1 = decode).  next_tokens [n] (host, may be NULL) = greedy argmax after each request's last token;
@@ -521,6 +521,11 @@ float nvk_bm_utilization(const nvk_block_manager *bm);                  /* ref :
 int  nvk_bm_allocate_for_request(nvk_block_manager *bm, int request_id, int num_tokens, int *ids, int cap);
 int  nvk_bm_allocate_block_for_request(nvk_block_manager *bm, int request_id);
 void nvk_bm_free_request(nvk_block_manager *bm, int request_id);
+/* Gives ONE block of a request back (no counterpart in the reference, whose per-request API only frees whole
+ * requests, :157-171): the block leaves the request's list AND the used set in one locked step, so a caller that
+ * has to undo part of a multi-block draw never leaves an id that a later free_request would free under another
+ * owner.  NVK_ERR_BAD_BLOCK when the request does not hold it. */
+int  nvk_bm_release_block_for_request(nvk_block_manager *bm, int request_id, int block_id);
 int  nvk_bm_get_request_blocks(nvk_block_manager *bm, int request_id, int *ids, int cap);
 int  nvk_bm_get_request_block_count(nvk_block_manager *bm, int request_id);
 int  nvk_bm_num_active_requests(nvk_block_manager *bm);

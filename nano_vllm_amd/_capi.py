@@ -183,6 +183,7 @@ SIGNATURES = {
     "nvk_bm_allocate_for_request": (C.c_int, [_vp, C.c_int, C.c_int, _i, C.c_int]),
     "nvk_bm_allocate_block_for_request": (C.c_int, [_vp, C.c_int]),
     "nvk_bm_free_request": (None, [_vp, C.c_int]),
+    "nvk_bm_release_block_for_request": (C.c_int, [_vp, C.c_int, C.c_int]),
     "nvk_bm_get_request_blocks": (C.c_int, [_vp, C.c_int, _i, C.c_int]),
     "nvk_bm_get_request_block_count": (C.c_int, [_vp, C.c_int]),
     "nvk_bm_num_active_requests": (C.c_int, [_vp]),

@@ -80,6 +80,10 @@ class BlockManager:
     def free_request(self, request_id: int) -> None:
         _capi.lib.nvk_bm_free_request(self._h, int(request_id))
 
+    def release_block_for_request(self, request_id: int, block_id: int) -> None:
+        """One block of a request back to the free set, out of the request's list in the same locked step."""
+        _capi.check(_capi.lib.nvk_bm_release_block_for_request(self._h, int(request_id), int(block_id)))
+
     def get_request_blocks(self, request_id: int) -> List[int]:
         n = _capi.lib.nvk_bm_get_request_block_count(self._h, int(request_id))
         ids = (C.c_int * max(n, 1))()

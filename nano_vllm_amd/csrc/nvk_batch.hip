@@ -92,6 +92,7 @@ struct nvk_batch
     // q / k / v / normalised-x rows of nvk_batch_layer_hidden (grown on demand, kept)
     float *h_q = nullptr, *h_k = nullptr, *h_v = nullptr, *h_xb = nullptr;
     size_t h_rows = 0, h_dim = 0, h_qdim = 0;
+    long long hidden_generation = 0; // bumped whenever the scratch rows move
 
     // counters for tests and tuning: how the tables reached the device
     long long full_uploads = 0, patch_steps = 0;
@@ -112,7 +113,7 @@ void release(nvk_batch *b)
 {
     if (!b)
         return;
-    nvk::DeviceScope scope(b->device);
+    nvk::DeviceScope scope(b->device); // (a release path: goes on whatever the switch returned)
     (void)hipDeviceSynchronize();
     if (b->plan)
         (void)nvk_plan_destroy(b->plan);
@@ -158,7 +159,7 @@ int nvk_batch_create(nvk_pool *pool, nvk_block_manager *bm, int max_seqs, int ma
     b->pool = pool, b->bm = bm, b->max_seqs = max_seqs, b->max_blocks = max_blocks_per_seq;
     b->block_size = geo[2], b->device = geo[5];
     b->row_len = geo[3] * geo[4], b->head_dim = geo[4];
-    nvk::DeviceScope  scope(b->device);
+    NVK_SCOPE(b->device);
     const size_t tab = (size_t)max_seqs * max_blocks_per_seq * sizeof(int);
     const size_t vec = (size_t)max_seqs * sizeof(int);
     hipError_t   e   = hipHostMalloc((void **)&b->h_tables, tab, hipHostMallocDefault);
@@ -230,7 +231,7 @@ int nvk_batch_finish_request(nvk_batch *b, int request_id)
     // Kernels of earlier steps may still be reading this request's blocks: they must be done
     // before the ids can be handed to another request.
     {
-        nvk::DeviceScope scope(b->device);
+        NVK_SCOPE(b->device);
         HIP_TRY(hipDeviceSynchronize());
     }
     nvk_bm_free_request(b->bm, request_id); // ref: BlockManager::free_request, block_manager.hpp:157-171
@@ -314,7 +315,7 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
         return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks (%d needed, %d free)", need,
                          nvk_bm_num_free_blocks(b->bm)); // the reference's text, model.hpp:184
 
-    nvk::DeviceScope scope(b->device);
+    NVK_SCOPE(b->device);
     hipStream_t st = stream_or_pool(b, stream);
     HIP_TRY(hipEventSynchronize(b->staged)); // the pinned buffers are ours again
 
@@ -330,7 +331,9 @@ int nvk_batch_begin_step(nvk_batch *b, const int *request_ids, int n, int n_head
             if (id < 0) { // another thread took blocks between the check and here: undo this step's allocations
                 for (int k = 0; k < n_patches; k++) {
                     Slot &u = b->slots[(size_t)slot_idx[(size_t)b->h_patches[3 * k]]];
-                    nvk_bm_free_block_safe(b->bm, u.blocks.back());
+                    // out of the request's list and back to the free set in one locked step: an id left in the list
+                    // would be freed again by free_request once it belongs to someone else
+                    (void)nvk_bm_release_block_for_request(b->bm, u.request_id, u.blocks.back());
                     u.blocks.pop_back();
                 }
                 return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks");
@@ -440,7 +443,7 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
         return nvk::fail(NVK_ERR_OOM, "Out of memory: no free blocks (%lld needed, %d free)", need,
                          nvk_bm_num_free_blocks(b->bm));
 
-    nvk::DeviceScope scope(b->device);
+    NVK_SCOPE(b->device);
     hipStream_t st = stream_or_pool(b, stream);
     HIP_TRY(hipEventSynchronize(b->staged));
     b->resident_valid = false; // rows of a mixed step are not the decode list: the next decode step re-sends its tables
@@ -454,7 +457,7 @@ int nvk_batch_begin_step_chunks(nvk_batch *b, const int *request_ids, const int 
                 for (int u = 0; u <= i; u++) {
                     Slot &t = b->slots[(size_t)slot_idx[(size_t)u]];
                     for (int r = (u == i ? k : fresh[(size_t)u]); r > 0; r--) {
-                        nvk_bm_free_block_safe(b->bm, t.blocks.back());
+                        (void)nvk_bm_release_block_for_request(b->bm, t.request_id, t.blocks.back());
                         t.blocks.pop_back();
                     }
                 }
@@ -526,7 +529,7 @@ int nvk_batch_layer(nvk_batch *b, int layer, float *q_dev, const float *k_rows_d
         return NVK_OK;
     if (!q_dev || !k_rows_dev || !v_rows_dev || !out_dev || rope_theta < 0.f)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_layer: bad arguments");
-    nvk::DeviceScope scope(b->device);
+    NVK_SCOPE(b->device);
     hipStream_t st = stream_or_pool(b, stream);
     if (b->chunked) {
         // decode part: rows [0, nd), one per request; prefill part: the chunks' rows packed behind them
@@ -589,6 +592,7 @@ int reserve_hidden_rows(nvk_batch *b, int rows, int dim)
     HIP_TRY(hipMalloc((void **)&b->h_v, r * b->row_len * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&b->h_xb, r * d * sizeof(float)));
     b->h_rows = r, b->h_dim = d, b->h_qdim = qdim;
+    b->hidden_generation++;
     return NVK_OK;
 }
 
@@ -630,7 +634,7 @@ int nvk::batch_layer_hidden_linked(nvk_batch *b, int layer, const float *xg_dev,
         return rows;
     if (!decode_rows_fuse(b, rows, dim, rope_theta))
         return nvk::fail(NVK_ERR_INVALID_ARG, "batch_layer_hidden_linked: not a step of one or two decoding rows");
-    nvk::DeviceScope scope(b->device);
+    NVK_SCOPE(b->device);
     int              rc = reserve_hidden_rows(b, rows, dim);
     if (rc != NVK_OK)
         return rc;
@@ -654,7 +658,7 @@ int nvk_batch_layer_hidden(nvk_batch *b, int layer, const float *x_dev, int dim,
     if (rows < 0)
         return rows;
     const size_t qdim = (size_t)b->n_heads * b->head_dim;
-    nvk::DeviceScope  scope(b->device);
+    NVK_SCOPE(b->device);
     hipStream_t  st = stream_or_pool(b, stream);
     int rc0 = reserve_hidden_rows(b, rows, dim);
     if (rc0 != NVK_OK)
@@ -692,8 +696,10 @@ int nvk_batch_graph_signature(const nvk_batch *b, long long *out8)
     out8[0] = (long long)b->step_ids.size();
     out8[1] = b->chunked ? 1 : 0;
     out8[2] = info[0], out8[3] = info[1], out8[4] = info[2], out8[5] = info[3];
-    out8[6] = nvk_pool_workspace_generation(b->pool);
-    out8[7] = (long long)(intptr_t)b->h_q ^ ((long long)b->n_heads << 48);
+    // everything a captured step bakes in by address, as generation counters (an address can come back from
+    // hipMalloc while its neighbours moved): the pool's workspace, the plan's work list, the scratch rows
+    out8[6] = nvk_pool_workspace_generation(b->pool) * 1000003LL + nvk::plan_generation(b->plan);
+    out8[7] = b->hidden_generation ^ ((long long)b->n_heads << 48);
     return NVK_OK;
 }
 

@@ -106,7 +106,10 @@ struct nvk_block_manager
         return true;
     }
 
-    int blocks_for(int num_tokens) const { return (num_tokens + block_size - 1) / block_size; } // ref :69
+    int blocks_for(int num_tokens) const // ref :69, in 64 bits (num_tokens near INT_MAX)
+    {
+        return (int)(((long long)num_tokens + block_size - 1) / block_size);
+    }
 };
 
 extern "C" {
@@ -171,6 +174,8 @@ int nvk_bm_is_free(const nvk_block_manager *bm, int block_id)
 
 float nvk_bm_utilization(const nvk_block_manager *bm)
 {
+    if (!bm || bm->num_blocks <= 0)
+        return 0.f; // (the reference divides 0 by 0 for an empty manager)
     return 1.0f - (static_cast<float>(bm->num_free) / bm->num_blocks); // ref :124, same expression
 }
 
@@ -180,7 +185,11 @@ int nvk_bm_allocate_for_request(nvk_block_manager *bm, int request_id, int num_t
         return 0;
     std::lock_guard<std::mutex> lock(bm->mutex);
     const int                   need = bm->blocks_for(num_tokens);
-    if (need > bm->num_free || need > cap)
+    if (need > cap) { // the caller's array, not the pool, is too small: say so (the count is 0 either way)
+        nvk::fail(NVK_ERR_INVALID_ARG, "nvk_bm_allocate_for_request: %d blocks needed, ids holds %d", need, cap);
+        return 0;
+    }
+    if (need > bm->num_free)
         return 0; // ref :263-265 returns an empty vector
     for (int i = 0; i < need; i++)
         ids[i] = bm->take_lowest();
@@ -200,6 +209,27 @@ int nvk_bm_allocate_block_for_request(nvk_block_manager *bm, int request_id)
     if (id >= 0)
         bm->request_blocks[request_id].push_back(id);
     return id;
+}
+
+int nvk_bm_release_block_for_request(nvk_block_manager *bm, int request_id, int block_id)
+{
+    if (!bm)
+        return NVK_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(bm->mutex);
+    auto                        it = bm->request_blocks.find(request_id);
+    if (it == bm->request_blocks.end())
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_bm_release_block_for_request: request %d holds no blocks", request_id);
+    std::vector<int> &mine = it->second;
+    for (size_t i = mine.size(); i-- > 0;)
+        if (mine[i] == block_id) {
+            mine.erase(mine.begin() + (long)i);
+            if (mine.empty())
+                bm->request_blocks.erase(it);
+            bm->give_back(block_id);
+            return NVK_OK;
+        }
+    return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_bm_release_block_for_request: request %d does not hold block %d", request_id,
+                     block_id);
 }
 
 void nvk_bm_free_request(nvk_block_manager *bm, int request_id)

@@ -5,6 +5,8 @@
 
 #include <atomic>
 
+#include "nvk_internal.h"
+
 namespace nvk {
 
 // Makes `device` current and restores the caller's device after; when it already is current (the usual case: one
@@ -30,6 +32,17 @@ struct DeviceScope
     DeviceScope(const DeviceScope &)            = delete;
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
+
+} // namespace nvk
+
+// Every entry point that works on a device opens with this: a failed switch is an error here, never a launch on
+// whatever device happened to be current (pointers of device A used on device B fail far from their cause).
+#define NVK_SCOPE(device)                                                                                              \
+    nvk::DeviceScope scope(device);                                                                                    \
+    if (!scope.ok)                                                                                                     \
+    return nvk::fail(NVK_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (int)(device))
+
+namespace nvk {
 
 // hipGetDeviceCount, asked once per process (0 when no device is visible or the runtime fails)
 inline int device_count_cached()

@@ -16,6 +16,9 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // device; the calling thread's current device must be `device`).
 int noalloc_scratch_on(int device, unsigned char **out);
 
+// Counts the times a plan's device arrays have moved (a captured graph that launches the plan holds their addresses).
+long long plan_generation(const nvk_plan *plan);
+
 // ---- RoPE + KV append in the epilogue of the q / k / v GEMV (one or two rows) -----------------
 // Where nvk_rope_append_kernel would put a step's rows: the layer's slabs, the step's tables and positions, the
 // frequency table.  Filled by nvk_paged_attn.hip, consumed by nvk_linear.hip.

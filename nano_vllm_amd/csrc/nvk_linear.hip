@@ -1164,7 +1164,7 @@ int nvk::linked_gemv(const NormLink &link, bool glu, float *out_dev, const float
     int rc = check_device(device, "linked_gemv");
     if (rc != NVK_OK)
         return rc;
-    nvk::DeviceScope   scope(device);
+    NVK_SCOPE(device);
     const float *const w[2]   = {w0_dev, w1_dev};
     float *const       out[2] = {out_dev, out_dev};
     const int          n[2]   = {out_dim, out_dim};
@@ -1202,7 +1202,7 @@ int nvk::qkv_rope_append(const RopeAppendTarget &t, float *q_dev, const float *x
     int rc = check_device(device, "qkv_rope_append");
     if (rc != NVK_OK)
         return rc;
-    nvk::DeviceScope   scope(device);
+    NVK_SCOPE(device);
     const float *const w[3]   = {wq_dev, wk_dev, wv_dev};
     float *const       out[3] = {q_dev, q_dev, q_dev}; // k and v go to the cache
     const int          n[3]   = {q_dim, t.row_len, t.row_len};
@@ -1237,7 +1237,7 @@ int nvk_batch_rms_norm_device(float *out_dev, const float *in_dev, const float *
         return rc;
     if (dim % 4 == 0 && (!aligned16(out_dev) || !aligned16(in_dev) || !aligned16(weight_dev)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_rms_norm_device: pointers must be 16-byte aligned");
-    nvk::DeviceScope scope(device);
+    NVK_SCOPE(device);
     hipLaunchKernelGGL(nvk::nvk_rms_norm_kernel<false>, dim3((unsigned)batch_size), dim3(256), 0, (hipStream_t)stream,
                        out_dev, const_cast<float *>(in_dev), (const float *)nullptr, weight_dev, dim, eps);
     HIP_TRY(hipGetLastError());
@@ -1255,7 +1255,7 @@ int nvk_batch_add_rms_norm_device(float *out_dev, float *x_dev, const float *add
         return rc;
     if (dim % 4 == 0 && (!aligned16(out_dev) || !aligned16(x_dev) || !aligned16(addend_dev) || !aligned16(weight_dev)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_add_rms_norm_device: pointers must be 16-byte aligned");
-    nvk::DeviceScope scope(device);
+    NVK_SCOPE(device);
     hipLaunchKernelGGL(nvk::nvk_rms_norm_kernel<true>, dim3((unsigned)batch_size), dim3(256), 0, (hipStream_t)stream,
                        out_dev, x_dev, addend_dev, weight_dev, dim, eps);
     HIP_TRY(hipGetLastError());
@@ -1270,7 +1270,7 @@ int nvk_batch_matmul_device(float *out_dev, const float *in_dev, const float *we
     int rc = check_device(device, "nvk_batch_matmul_device");
     if (rc != NVK_OK || batch_size == 0)
         return rc;
-    nvk::DeviceScope scope(device);
+    NVK_SCOPE(device);
     return launch_linear(in_dev, batch_size, in_dim, &weight_dev, &out_dev, &out_dim, 1, device, (hipStream_t)stream,
                          "nvk_batch_matmul_device");
 }
@@ -1285,7 +1285,7 @@ int nvk_batch_matmul2_device(float *out_a_dev, float *out_b_dev, const float *in
     int rc = check_device(device, "nvk_batch_matmul2_device");
     if (rc != NVK_OK || batch_size == 0)
         return rc;
-    nvk::DeviceScope        scope(device);
+    NVK_SCOPE(device);
     const float *const w[2]   = {weight_a_dev, weight_b_dev};
     float *const       out[2] = {out_a_dev, out_b_dev};
     const int          n[2]   = {out_dim_a, out_dim_b};
@@ -1301,7 +1301,7 @@ int nvk_batch_swiglu_ffn_device(float *hb_dev, float *hb2_dev, const float *in_d
     int rc = check_device(device, "nvk_batch_swiglu_ffn_device");
     if (rc != NVK_OK || batch_size == 0)
         return rc;
-    nvk::DeviceScope   scope(device);
+    NVK_SCOPE(device);
     const float *const w[2]   = {w_gate_dev, w_up_dev};
     float *const       out[2] = {hb_dev, hb2_dev};
     const int          n[2]   = {hidden_dim, hidden_dim};
@@ -1337,7 +1337,7 @@ int nvk_qkv_project_device(float *q_dev, float *k_dev, float *v_dev, const float
             return rc;
         act = xb_dev;
     }
-    nvk::DeviceScope        scope(device);
+    NVK_SCOPE(device);
     const float *const w[3]   = {wq_dev, wk_dev, wv_dev}; // model.hpp:164-166
     float *const       out[3] = {q_dev, k_dev, v_dev};
     const int          n[3]   = {q_dim, kv_dim, kv_dim};

@@ -145,7 +145,8 @@ struct nvk_model
     // while nothing it bakes in has changed: with few requests a step is hundreds of short dependent kernels and
     // the launch gaps, not the kernels, set its time.
     bool            use_graphs = true;
-    bool            use_linked = true; // single-row steps: the norms ride between the GEMVs (nvk::NormLink)
+    bool            use_linked = false; // opt-in (nvk_model_use_linked_norms): the norms of 1-16 row steps ride between the
+                                        // GEMVs (nvk::NormLink) -- faster, a few ulp from the separate norm kernels
     int             graph_failures = 0;
     hipGraphExec_t  graph_exec = nullptr;
     long long       graph_sig[9] = {0};
@@ -158,7 +159,7 @@ void release(nvk_model *m)
 {
     if (!m)
         return;
-    nvk::DeviceScope scope(m->device);
+    nvk::DeviceScope scope(m->device); // (a release path: goes on whatever the switch returned)
     (void)hipDeviceSynchronize();
     if (m->graph_exec)
         (void)hipGraphExecDestroy(m->graph_exec);
@@ -281,7 +282,7 @@ int nvk_model_load(const char *checkpoint_path, int block_size, int num_blocks, 
     }
     m->dim = D, m->hidden_dim = Hd, m->n_layers = L, m->n_heads = H, m->n_kv_heads = KV, m->vocab = V, m->max_seq_len = S;
     m->head_dim = hd, m->shared = !has_head, m->device = device, m->max_seqs = max_seqs;
-    nvk::DeviceScope scope(device);
+    NVK_SCOPE(device);
 
     // stream the file to the device in 64 MiB pieces through one pinned buffer
     hipError_t e = hipMalloc((void **)&m->weights, total * sizeof(float));
@@ -410,7 +411,7 @@ int nvk_model_use_graphs(nvk_model *m, int on)
     m->use_graphs     = on != 0;
     m->graph_failures = 0;
     if (!on && m->graph_exec) {
-        nvk::DeviceScope scope(m->device);
+        NVK_SCOPE(m->device);
         (void)hipStreamSynchronize(m->stream);
         (void)hipGraphExecDestroy(m->graph_exec);
         m->graph_exec = nullptr;
@@ -444,7 +445,7 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
     }
     if (rows > 0x3fffffffLL)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: %lld rows in one step", rows);
-    nvk::DeviceScope scope(m->device);
+    NVK_SCOPE(m->device);
     int         rc = reserve_rows(m, (int)rows);
     if (rc != NVK_OK)
         return rc;

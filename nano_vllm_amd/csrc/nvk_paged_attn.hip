@@ -430,6 +430,7 @@ struct nvk_plan
     int          *counters = nullptr; // [0] = n_items, [1 + s] = chunks of sequence s
     size_t        cap_items = 0, cap_seqs = 0;
     int           item_bound = 0; // grid.x: at least as many workgroups as items
+    long long     generation = 0; // bumped whenever items / counters move (a captured graph holds their addresses)
     // direct indexing (NVK_DECODE_UNIFORM / NVK_DECODE_NO_PLAN): no work list; the kernels read the lengths themselves
     bool          direct = false;
     const int    *ctx_lens_dev = nullptr; // direct: the caller's lengths (null: every row holds uniform_ctx tokens)
@@ -455,6 +456,7 @@ int plan_reserve(nvk_plan *plan, size_t items, size_t seqs, hipStream_t stream)
         const size_t want = std::max(items, (size_t)1024);
         HIP_TRY(hipMalloc(&plan->items, want * sizeof(nvk::WorkItem)));
         plan->cap_items = want;
+        plan->generation++;
     }
     if (seqs > plan->cap_seqs) {
         if (plan->counters) {
@@ -466,6 +468,7 @@ int plan_reserve(nvk_plan *plan, size_t items, size_t seqs, hipStream_t stream)
         const size_t want = std::max(seqs, (size_t)1024);
         HIP_TRY(hipMalloc(&plan->counters, (want + 1) * sizeof(int)));
         plan->cap_seqs = want;
+        plan->generation++;
     }
     return NVK_OK;
 }
@@ -855,9 +858,42 @@ int validate_chunk_tables(const nvk_pool *pool, int num_seqs, const int *tables,
 // thread-local binding for the drop-in entry point
 thread_local nvk_pool *t_bound_pool  = nullptr;
 thread_local int       t_bound_layer = 0;
-// thread-local scratch pool for the unbound (host-slab) form of the drop-in
-thread_local nvk_pool *t_scratch_pool = nullptr;
+// (the unbound, host-slab form of the drop-in keeps a thread-local staging pool: ThreadSlabs below)
 
+
+// ---- host-slab mirrors (NVK_HOST_CACHE_APPEND_ONLY) --------------------------
+// The drop-in entry points get the engine's HOST slabs.  Re-staging the whole context on every call
+// is always correct and PCIe-bound; but the reference engine only ever appends: between two calls
+// for the same slab exactly one new token row is written (model.hpp:190-207) and num_tokens grows by
+// one (model.hpp:397).  Under that promise a device mirror per slab keeps what it has and only the
+// rows it has not seen cross PCIe.  Any call that is not "the previous call plus one token" on the
+// same slab restages everything, so a new request (pos back to 0) is handled without being told.
+struct HostMirror
+{
+    const float *k_host = nullptr, *v_host = nullptr;
+    nvk_pool    *pool   = nullptr; // one layer; local block ids
+    int          last_tokens = -1;
+    bool         contiguous  = false; // mirror of a contiguous cache (nvk_standard_attention): one row counter
+    std::unordered_map<int, int> local_of; // physical block id of the host slab -> block of `pool`
+    std::vector<int>             rows_staged; // per local block
+    // the promise's witness: a copy of the last K row staged and where it sits in the host slab.  A slab that was
+    // freed and allocated again at the same address, or rewritten in place, almost surely no longer holds these
+    // bytes there: then nothing staged is trusted (a cheap check, one row; it cannot prove the promise kept).
+    std::vector<float> witness;
+    size_t             witness_at = 0; // float offset into k_host
+};
+
+// The calling thread's device-side state behind the host-slab forms of the drop-in entry points; released when
+// the thread ends (each mirror and the staging pool hold device memory).
+struct ThreadSlabs
+{
+    nvk_pool               *scratch_pool = nullptr;
+    std::vector<HostMirror> mirrors;
+    ~ThreadSlabs();
+};
+thread_local ThreadSlabs t_slabs;
+#define t_scratch_pool (t_slabs.scratch_pool)
+#define t_mirrors (t_slabs.mirrors)
 
 // The calling thread's one-layer staging pool for the host-slab forms of the
 // drop-in entry points, (re)created when the geometry changes or it is too small.
@@ -881,23 +917,6 @@ int scratch_pool_for(int block_size, int n_kv_heads, int head_dim, int nblk, nvk
     return NVK_OK;
 }
 
-// ---- host-slab mirrors (NVK_HOST_CACHE_APPEND_ONLY) --------------------------
-// The drop-in entry points get the engine's HOST slabs.  Re-staging the whole context on every call
-// is always correct and PCIe-bound; but the reference engine only ever appends: between two calls
-// for the same slab exactly one new token row is written (model.hpp:190-207) and num_tokens grows by
-// one (model.hpp:397).  Under that promise a device mirror per slab keeps what it has and only the
-// rows it has not seen cross PCIe.  Any call that is not "the previous call plus one token" on the
-// same slab restages everything, so a new request (pos back to 0) is handled without being told.
-struct HostMirror
-{
-    const float *k_host = nullptr, *v_host = nullptr;
-    nvk_pool    *pool   = nullptr; // one layer; local block ids
-    int          last_tokens = -1;
-    bool         contiguous  = false; // mirror of a contiguous cache (nvk_standard_attention): one row counter
-    std::unordered_map<int, int> local_of; // physical block id of the host slab -> block of `pool`
-    std::vector<int>             rows_staged; // per local block
-};
-thread_local std::vector<HostMirror> t_mirrors;
 thread_local int                     t_host_policy = NVK_HOST_CACHE_RESTAGE;
 thread_local long long               t_staged_bytes = 0; // H2D bytes of K/V rows moved by the drop-in entry points
 
@@ -906,6 +925,29 @@ void drop_mirror(HostMirror &m)
     if (m.pool)
         nvk_pool_destroy(m.pool);
     m = HostMirror();
+}
+
+ThreadSlabs::~ThreadSlabs()
+{
+    for (HostMirror &m : mirrors)
+        drop_mirror(m);
+    mirrors.clear();
+    if (scratch_pool)
+        nvk_pool_destroy(scratch_pool);
+    scratch_pool = nullptr;
+}
+
+// Does the host slab still hold the row the mirror staged last, where it staged it?
+bool witness_holds(const HostMirror &m)
+{
+    return m.witness.empty()
+           || std::memcmp(m.k_host + m.witness_at, m.witness.data(), m.witness.size() * sizeof(float)) == 0;
+}
+
+void keep_witness(HostMirror &m, size_t row_at, size_t row_floats)
+{
+    m.witness.assign(m.k_host + row_at, m.k_host + row_at + row_floats);
+    m.witness_at = row_at;
 }
 
 // Finds or creates the mirror of (key_cache, value_cache) with room for `need_blocks` blocks.
@@ -1068,7 +1110,7 @@ int nvk_pool_set_rope_theta(nvk_pool *pool, float rope_theta)
 {
     if (!pool || !(rope_theta > 0.f) || pool->head_dim % 2 != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_set_rope_theta: bad arguments");
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     return ensure_rope_table(pool, rope_theta);
 }
 
@@ -1149,7 +1191,7 @@ int nvk_pool_synchronize(nvk_pool *pool)
 {
     if (!pool)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_synchronize: null pool");
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     HIP_TRY(hipStreamSynchronize(pool->stream));
     return NVK_OK;
 }
@@ -1168,7 +1210,7 @@ int nvk_pool_append(nvk_pool *pool, int layer, int physical_block, int block_off
     if (block_offset < 0 || block_offset >= pool->block_size)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append: offset %d outside [0,%d)", block_offset,
                          pool->block_size);
-    nvk::DeviceScope  scope(pool->device);
+    NVK_SCOPE(pool->device);
     const size_t row = (size_t)pool->row_len();
     const size_t at  = ((size_t)physical_block * pool->block_size + block_offset) * row;
     HIP_TRY(hipMemcpyAsync(pool->k_layer(layer) + at, k_row, row * sizeof(float), hipMemcpyHostToDevice, pool->stream));
@@ -1188,7 +1230,7 @@ int nvk_pool_append_batch(nvk_pool *pool, int layer, int num_seqs, const float *
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_append_batch: bad arguments");
     if (num_seqs == 0)
         return NVK_OK;
-    nvk::DeviceScope  scope(pool->device);
+    NVK_SCOPE(pool->device);
     const int    row = pool->row_len();
     const float *dk = k_rows, *dv = v_rows;
     const int   *dt = block_tables, *dp = positions;
@@ -1249,7 +1291,7 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_batch: head_dim must be even");
     if (num_seqs == 0)
         return NVK_OK;
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     hipStream_t st   = (ptr_kind == NVK_PTR_DEVICE && stream) ? (hipStream_t)stream : pool->stream;
     const int   hd   = pool->head_dim;
     const int   half = hd / 2;
@@ -1322,7 +1364,7 @@ int nvk::pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, co
         return rc;
     if (!(rope_theta > 0.f) || !block_tables_dev || !positions_dev || max_blocks <= 0 || !out || pool->head_dim % 2 != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "pool_rope_append_target: bad arguments");
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     rc = ensure_rope_table(pool, rope_theta);
     if (rc != NVK_OK)
         return rc;
@@ -1343,7 +1385,7 @@ int nvk_pool_upload_block(nvk_pool *pool, int layer, int physical_block, const f
     if (physical_block < 0 || physical_block >= pool->num_blocks)
         return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_upload_block: block %d outside [0,%d)", physical_block,
                          pool->num_blocks);
-    nvk::DeviceScope  scope(pool->device);
+    NVK_SCOPE(pool->device);
     const size_t blk = (size_t)pool->block_size * pool->row_len();
     if (k_block)
         HIP_TRY(hipMemcpyAsync(pool->k_layer(layer) + physical_block * blk, k_block, blk * sizeof(float),
@@ -1363,7 +1405,7 @@ int nvk_pool_download_block(nvk_pool *pool, int layer, int physical_block, float
     if (physical_block < 0 || physical_block >= pool->num_blocks)
         return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_download_block: block %d outside [0,%d)", physical_block,
                          pool->num_blocks);
-    nvk::DeviceScope  scope(pool->device);
+    NVK_SCOPE(pool->device);
     const size_t blk = (size_t)pool->block_size * pool->row_len();
     if (k_block)
         HIP_TRY(hipMemcpyAsync(k_block, pool->k_layer(layer) + physical_block * blk, blk * sizeof(float),
@@ -1390,7 +1432,7 @@ int nvk_pool_gather(nvk_pool *pool, int layer, const int *block_table, int num_t
         if (block_table[i] < 0 || block_table[i] >= pool->num_blocks)
             return nvk::fail(NVK_ERR_BAD_BLOCK, "nvk_pool_gather: table[%d]=%d outside [0,%d)", i, block_table[i],
                              pool->num_blocks);
-    nvk::DeviceScope  scope(pool->device);
+    NVK_SCOPE(pool->device);
     const size_t out_b = (size_t)num_tokens * pool->head_dim * sizeof(float);
     const size_t out_a = (out_b + 255) / 256 * 256;
     const size_t tab_b = (size_t)nblk * sizeof(int);
@@ -1416,7 +1458,7 @@ int nvk_pool_fill_uniform(nvk_pool *pool, int layer, uint64_t seed_k, uint64_t s
     int rc = check_pool_layer(pool, layer, "nvk_pool_fill_uniform");
     if (rc != NVK_OK)
         return rc;
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     const dim3  grid((unsigned)(pool->num_cus * 8)), block(256);
     hipLaunchKernelGGL(nvk::nvk_fill_kernel, grid, block, 0, pool->stream, pool->k_layer(layer), seed_k,
                        (uint64_t)pool->layer_floats);
@@ -1432,7 +1474,7 @@ int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int ma
 {
     if (!pool || num_seqs < 0 || max_ctx < 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_reserve_workspace: bad arguments");
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     LaunchShape shape;
     int rc = make_shape(pool, num_seqs, n_heads, max_ctx, chunk_tokens > 0 ? NVK_DECODE_SPLIT_K : NVK_DECODE_AUTO,
                         chunk_tokens, &shape);
@@ -1486,10 +1528,14 @@ int nvk_plan_build(nvk_plan *plan, int num_seqs, int n_heads, const int *ctx_len
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: bad arguments");
     if (!decode_flags_ok(flags))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_plan_build: flags 0x%x", flags);
-    nvk::DeviceScope scope(plan->pool->device);
+    NVK_SCOPE(plan->pool->device);
     return build_plan(plan, num_seqs, n_heads, ctx_lens_dev, max_ctx, flags, chunk_tokens,
                       stream ? (hipStream_t)stream : plan->pool->stream);
 }
+
+} // extern "C"
+long long nvk::plan_generation(const nvk_plan *plan) { return plan ? plan->generation : -1; }
+extern "C" {
 
 int nvk_plan_info(const nvk_plan *plan, int *out4)
 {
@@ -1508,7 +1554,7 @@ int nvk_decode_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const fl
         return rc;
     if (!plan || max_blocks <= 0 || (plan->num_seqs > 0 && (!q_dev || !block_tables_dev || !out_dev)))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_planned: bad arguments");
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     return enqueue_planned(pool, layer, plan, q_dev, block_tables_dev, max_blocks, out_dev,
                            stream ? (hipStream_t)stream : pool->stream, nullptr, nullptr);
 }
@@ -1525,7 +1571,7 @@ int nvk_decode_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, cons
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: bad arguments");
     if (!decode_flags_ok(flags))
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_device: flags 0x%x", flags);
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     return enqueue_decode(pool, layer, num_seqs, n_heads, q_dev, block_tables_dev, max_blocks, ctx_lens_dev, max_ctx,
                           out_dev, flags, chunk_tokens, stream ? (hipStream_t)stream : pool->stream);
 }
@@ -1668,7 +1714,7 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
     if (std::all_of(ctx_lens, ctx_lens + num_seqs, [&](int c) { return c == max_ctx; }))
         flags |= NVK_DECODE_UNIFORM; // every row holds max_ctx tokens: the plan's order is the direct order
 
-    nvk::DeviceScope  scope(pool->device);
+    NVK_SCOPE(pool->device);
     const size_t q_b   = (size_t)num_seqs * n_heads * pool->head_dim * sizeof(float);
     const size_t q_a   = (q_b + 255) / 256 * 256;
     const size_t tab_b = (size_t)num_seqs * max_blocks * sizeof(int);
@@ -1799,7 +1845,7 @@ int nvk_decode_bench_layers(nvk_pool *pool, int first_layer, int n_rotate, int n
     if (iters < 0 || warmup < 0 || num_seqs <= 0 || iters > 100000 || replan_every < 1)
         return nvk::fail(NVK_ERR_INVALID_ARG,
                          "nvk_decode_bench: need 0 <= iters <= 100000, warmup >= 0, num_seqs > 0, replan_every >= 1");
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     hipStream_t st   = pool->stream;
     nvk_plan   *plan = nullptr;
     rc               = own_plan_of(pool, &plan);
@@ -1892,7 +1938,7 @@ int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_h
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_rope_append_chunks: ptr_kind %d", ptr_kind);
     if (num_seqs == 0)
         return NVK_OK;
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     hipStream_t st = (ptr_kind == NVK_PTR_DEVICE && stream) ? (hipStream_t)stream : pool->stream;
     if (ptr_kind == NVK_PTR_HOST) {
         rc = validate_chunk_tables(pool, num_seqs, block_tables, max_blocks, chunk_starts, chunk_lens,
@@ -1960,7 +2006,7 @@ int nvk_prefill_device(nvk_pool *pool, int layer, int num_seqs, int n_heads, con
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_prefill_device: flags %d", flags);
     if (num_seqs == 0)
         return NVK_OK;
-    nvk::DeviceScope scope(pool->device);
+    NVK_SCOPE(pool->device);
     hipStream_t st = stream ? (hipStream_t)stream : pool->stream;
     if (n_heads % pool->n_kv_heads != 0)
         return nvk::fail(NVK_ERR_INVALID_ARG, "n_heads=%d is not a positive multiple of n_kv_heads=%d", n_heads,
@@ -2065,7 +2111,7 @@ int nvk_prefill(nvk_pool *pool, int layer, int num_seqs, int n_heads, const floa
         return rc;
     if (total == 0)
         return NVK_OK;
-    nvk::DeviceScope  scope(pool->device);
+    NVK_SCOPE(pool->device);
     const size_t q_b   = (size_t)total * n_heads * pool->head_dim * sizeof(float);
     const size_t tab_b = (size_t)num_seqs * max_blocks * sizeof(int);
     auto         al    = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -2144,8 +2190,9 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
         if (rc != NVK_OK)
             return rc;
         nvk_pool   *mp = m->pool;
-        nvk::DeviceScope scope(mp->device);
-        if (num_tokens != m->last_tokens + 1) // not "the previous call plus one token": trust nothing staged
+        NVK_SCOPE(mp->device);
+        // not "the previous call plus one token", or the slab no longer holds what was staged last: trust nothing staged
+        if (num_tokens != m->last_tokens + 1 || !witness_holds(*m))
             std::fill(m->rows_staged.begin(), m->rows_staged.end(), 0);
         for (int i = 0; i < nblk; i++) {
             auto it = m->local_of.find(block_table[i]);
@@ -2176,6 +2223,8 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
             local[(size_t)i] = lb;
         }
         m->last_tokens = num_tokens;
+        keep_witness(*m, (size_t)block_table[(num_tokens - 1) / block_size] * blk + (size_t)((num_tokens - 1) % block_size) * row,
+                     row);
         return nvk_decode(mp, 0, 1, n_heads, q, local.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
     }
 
@@ -2183,7 +2232,7 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
     int       rc = scratch_pool_for(block_size, n_kv_heads, head_dim, nblk, &sp);
     if (rc != NVK_OK)
         return rc;
-    nvk::DeviceScope scope(sp->device);
+    NVK_SCOPE(sp->device);
     for (int i = 0; i < nblk; i++) {
         // only the rows of the block that the sequence has reached (the last block is partly filled)
         const size_t rows = (size_t)std::min(block_size, num_tokens - i * block_size) * row;
@@ -2225,11 +2274,11 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
         int         rc = mirror_for(key_cache, value_cache, kBlock, n_kv_heads, head_dim, nblk, true, &m);
         if (rc != NVK_OK)
             return rc;
-        nvk::DeviceScope scope(m->pool->device);
+        NVK_SCOPE(m->pool->device);
         if (m->rows_staged.empty())
             m->rows_staged.push_back(0); // one counter: rows of the contiguous cache already on the device
         int &have = m->rows_staged[0];
-        if (num_tokens != m->last_tokens + 1)
+        if (num_tokens != m->last_tokens + 1 || !witness_holds(*m))
             have = 0;
         if (have < num_tokens) {
             const size_t at = (size_t)have * row, n = (size_t)(num_tokens - have) * row;
@@ -2241,6 +2290,7 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
             have = num_tokens;
         }
         m->last_tokens = num_tokens;
+        keep_witness(*m, (size_t)(num_tokens - 1) * row, row);
         return nvk_decode(m->pool, 0, 1, n_heads, q, ident.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);
     }
 
@@ -2248,7 +2298,7 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
     int       rc = scratch_pool_for(kBlock, n_kv_heads, head_dim, nblk, &sp);
     if (rc != NVK_OK)
         return rc;
-    nvk::DeviceScope  scope(sp->device);
+    NVK_SCOPE(sp->device);
     const size_t bytes = (size_t)num_tokens * row * sizeof(float);
     HIP_TRY(hipMemcpyAsync(sp->k_layer(0), key_cache, bytes, hipMemcpyHostToDevice, sp->stream));
     HIP_TRY(hipMemcpyAsync(sp->v_layer(0), value_cache, bytes, hipMemcpyHostToDevice, sp->stream));

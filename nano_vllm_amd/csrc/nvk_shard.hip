@@ -227,7 +227,7 @@ int nvk_shard_all_gather_out(nvk_shard *s, const float *out_local_dev, float *ga
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_shard_all_gather_out: bad arguments");
     if (num_seqs == 0)
         return NVK_OK;
-    nvk::DeviceScope scope(s->device);
+    NVK_SCOPE(s->device);
     const size_t count = (size_t)num_seqs * (s->n_heads / s->world) * head_dim;
     const int    e = g_rccl.all_gather(out_local_dev, gathered_dev, count, kNcclFloat, s->comm,
                                        stream ? (hipStream_t)stream : s->comm_stream);
@@ -251,7 +251,7 @@ int nvk_shard_decode_gather(nvk_shard *s, nvk_pool *pool, int layer, int num_seq
         return nvk::fail(NVK_ERR_INVALID_ARG,
                          "nvk_shard_decode_gather: the pool holds %d kv-heads on device %d, this rank's shard is %d on %d",
                          geo[3], geo[5], s->n_kv_heads / s->world, s->device);
-    nvk::DeviceScope scope(s->device);
+    NVK_SCOPE(s->device);
     void *pool_stream = nullptr;
     rc                = nvk_pool_stream(pool, &pool_stream);
     if (rc != NVK_OK)
@@ -280,7 +280,7 @@ int nvk_shard_wait_gather(nvk_shard *s, int buffer, void *stream)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_shard_wait_gather: bad arguments");
     if (!s->pending[buffer])
         return NVK_OK;
-    nvk::DeviceScope scope(s->device);
+    NVK_SCOPE(s->device);
     if (stream)
         HIP_TRY_S(hipStreamWaitEvent((hipStream_t)stream, s->gathered[buffer], 0));
     else

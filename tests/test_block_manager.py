@@ -137,3 +137,42 @@ def test_model_style_shared_free_list():
     for layer in range(L):
         assert tables[layer] == [layer + L * i for i in range(16)]
     assert bm.get_num_free_blocks() == 256 - 96
+
+
+def test_release_block_for_request_undoes_a_partial_draw():
+    """What nvk_batch's roll-back needs when another thread took blocks between its check and its draw: a block
+    given back must also leave its request's list, or free_request would later free it under its next owner
+    (two sequences on one KV block).  The reference's per-request API has no such call (block_manager.hpp:157-171
+    frees whole requests only)."""
+    import nano_vllm_amd as nv
+
+    bm = nv.BlockManager(6, 16)
+    a = [bm.allocate_block_for_request(7) for _ in range(3)]  # request 7 draws 0, 1, 2
+    assert a == [0, 1, 2]
+    bm.release_block_for_request(7, 2)                         # roll the last one back
+    assert bm.get_request_blocks(7) == [0, 1] and bm.is_free(2) and bm.get_num_free_blocks() == 4
+    assert bm.allocate_block_for_request(9) == 2               # the id goes to another request
+    bm.free_request(7)                                         # must free 0 and 1 only
+    assert not bm.is_free(2) and bm.get_request_blocks(9) == [2]
+    assert bm.is_free(0) and bm.is_free(1) and bm.get_num_active_requests() == 1
+    with pytest.raises(nv.NvkError) as e:
+        bm.release_block_for_request(9, 5)                     # not held by that request
+    assert e.value.code == nv._capi.ERR_BAD_BLOCK
+    with pytest.raises(nv.NvkError):
+        bm.release_block_for_request(7, 0)                     # request 7 holds nothing any more
+    bm.release_block_for_request(9, 2)
+    assert bm.get_num_active_requests() == 0 and bm.get_num_free_blocks() == 6
+
+
+def test_small_guards_of_the_c_abi():
+    import ctypes as C
+
+    import nano_vllm_amd as nv
+    lib = nv._capi.lib
+    lib.nvk_bm_utilization.restype = C.c_float
+    assert lib.nvk_bm_utilization(None) == 0.0
+    bm = nv.BlockManager(4, 16)
+    assert bm.allocate_for_request(1, 2 ** 31 - 1) == []       # 134 M blocks wanted, computed without overflow
+    ids = (C.c_int * 1)()
+    assert lib.nvk_bm_allocate_for_request(bm._h, 3, 40, ids, 1) == 0  # 3 blocks needed, room for 1: nothing drawn
+    assert b"ids holds 1" in lib.nvk_last_error() and bm.get_num_free_blocks() == 4

@@ -293,6 +293,13 @@ def test_config5a_many_short_sequences():
     _full_size_check(work, list(range(0, 512, 37)), [(nv.AUTO, 0), (nv.SINGLE_PASS, 0)])
 
 
+def test_config5b_one_gpu_share_full_size():
+    """configs[4], the bandwidth-scaling point (5b): one GPU's 512 sequences x 2K context, 8 GiB of KV."""
+    work = wl.config5b(512)
+    assert work.total_tokens == 512 * 2048
+    _full_size_check(work, [0, 200, 511], [(nv.AUTO, 0), (nv.SPLIT_K, 512)])
+
+
 def test_block_placement_does_not_change_bits():
     """Paged == contiguous: moving the same rows to other physical blocks leaves every output bit unchanged."""
     case = ATTENTION_CASES[8]  # 32/8/128, 2048 tokens

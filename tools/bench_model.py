@@ -27,7 +27,7 @@ ap.add_argument("--preset", default="tinyllama", choices=sorted(PRESETS))
 ap.add_argument("--seqs", type=int, default=64)
 ap.add_argument("--ctx", type=int, default=512)
 ap.add_argument("--steps", type=int, default=16)
-ap.add_argument("--no-linked", action="store_true", help="run the norms of 1-16 row steps as kernels of their own")
+ap.add_argument("--linked", action="store_true", help="carry the norms of 1-16 row steps between the GEMVs (opt-in: a few ulp from the separate kernels)")
 ap.add_argument("--no-graphs", action="store_true", help="launch every decode step's kernels directly (no hipGraph replay)")
 ap.add_argument("--chunk", type=int, default=2048, help="prompt tokens fed per request and step during prefill")
 args = ap.parse_args()
@@ -59,8 +59,8 @@ t0 = time.perf_counter()
 with nv.LlamaModel(path, bs, blocks, max_seqs=args.seqs) as m:
     if args.no_graphs:
         m.use_graphs(False)
-    if args.no_linked:
-        m.use_linked_norms(False)
+    if args.linked:
+        m.use_linked_norms(True)
     print(f"{args.preset}: dim {D}, {L} layers, {H}/{KV} heads x {hd}, hidden {Hd}, vocab {V}; loaded in "
           f"{time.perf_counter() - t0:.1f} s; {args.seqs} requests x {args.ctx} prompt tokens", flush=True)
     rng = np.random.default_rng(2)
