@@ -14,7 +14,7 @@ LIB     := nano_vllm_amd/libnvk_paged_attn.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -I$(CSRC) \
             -Wall -Wno-unused-function -fno-gpu-rdc
 
-.PHONY: all lib cli oracle ref clean asm
+.PHONY: all lib cli oracle ref clean asm asan
 all: lib cli oracle ref
 
 lib: $(LIB)
@@ -33,6 +33,19 @@ asm:
 	mkdir -p build/asm
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) -save-temps=obj -c \
 	   -Rpass-analysis=kernel-resource-usage -o build/asm/nvk_paged_attn.o $(CSRC)/nvk_paged_attn.hip 2> build/resource_usage.txt
+
+# Host code under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only; the pool runs no GPU sanitizer):
+# the block allocator, the tokenizer and the CPU checker behind tests/asan_driver.cpp, and the command line
+# (its JSON reader and argument handling) as an instrumented executable over the normal library.
+# tests/test_sanitizers.py builds and runs them on traces, random texts, and short / damaged input files.
+SAN := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1 -static-libasan
+asan:
+	mkdir -p build/asan
+	gcc $(SAN) -std=c11 -c -o build/asan/nvk_oracle.o oracle/nvk_oracle.c
+	g++ $(SAN) -static-libubsan -std=c++17 -Wall -Iinclude -I$(CSRC) -o build/asan/asan_driver tests/asan_driver.cpp tests/asan_stubs.cpp \
+	    $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp build/asan/nvk_oracle.o -lpthread -lm
+	g++ $(SAN) -static-libubsan -std=c++17 -Wall -Iinclude -o build/asan/nvk_run_asan tools/nvk_run.cpp -Lnano_vllm_amd -lnvk_paged_attn \
+	    -Wl,-rpath,'$$ORIGIN/../../nano_vllm_amd'
 
 oracle:
 	$(MAKE) -C oracle oracle

@@ -47,6 +47,10 @@ def test_argument_and_path_errors(model_dir, tmp_path):
     assert r.returncode == 1 and b"has empty prompt" in r.stderr  # json_parser.hpp:318-320
     bad.write_text('{"requests": [{"prompt": "a" "max_tokens": 3}]}')
     assert run(model_dir, "--input-json", str(bad)).returncode == 1
+    # the reference samples by default (-t 1.0, src/main.cpp:22); this build only decodes greedily and says so
+    # instead of producing another kind of output silently
+    r = run(model_dir, "-i", "hello", "-n", "3")
+    assert r.returncode == 2 and b"no sampler" in r.stderr and b"--greedy" in r.stderr
 
 
 def test_fails_loudly_without_a_gpu(model_dir):

@@ -10,7 +10,7 @@
 // Differences, on purpose: the whole forward pass runs on the GPU (nvk_model_*); a prompt is prefilled as one
 // chunk; --input-json with -b > 1 really batches (the reference forms the batch and then runs each request alone,
 // batched_runner.hpp:84-85); sampling is greedy whatever -t / -p say (the reference seeds its sampler from the
-// clock, so only greedy output is reproducible) -- a temperature other than 0 is reported and ignored.
+// clock, so only greedy output is reproducible) -- a temperature other than 0 is an error unless --greedy is given.
 // Host-only C++ over the C ABI; no CPU path for the model.
 
 #include <sys/stat.h>
@@ -257,7 +257,7 @@ std::vector<int> encode(const nvk_tokenizer *tok, const std::string &text)
 void usage()
 {
     fprintf(stderr, "usage: nvk_run <model dir | model.bin> (-i PROMPT | --input-json FILE) [-n STEPS] "
-                    "[-b MAX_BATCH] [-t TEMPERATURE] [-p TOP_P] [--block-size N] [--num-blocks N] [--device N]\n");
+                    "[-b MAX_BATCH] [-t TEMPERATURE (0, or any with --greedy)] [-p TOP_P] [--greedy] [--block-size N] [--num-blocks N] [--device N]\n");
 }
 
 } // namespace
@@ -267,6 +267,7 @@ int main(int argc, char **argv)
     std::string path, prompt, input_json;
     int         max_batch = 1, steps = 256, block_size = 16, num_blocks = 0, device = 0; // main.cpp:19-26, model.hpp:35-36
     float       temperature = 1.0f, top_p = 0.9f;
+    bool        greedy = false; // --greedy: decode greedily whatever temperature a request asks for
     for (int a = 1; a < argc; a++) {
         const std::string k    = argv[a];
         auto              next = [&]() -> const char * {
@@ -288,6 +289,8 @@ int main(int argc, char **argv)
             top_p = (float)atof(next());
         else if (k == "-n" || k == "--steps")
             steps = atoi(next());
+        else if (k == "--greedy")
+            greedy = true;
         else if (k == "--block-size")
             block_size = atoi(next());
         else if (k == "--num-blocks")
@@ -330,9 +333,18 @@ int main(int argc, char **argv)
         fprintf(stderr, "[ERROR] %s\n", e.what());
         return 1;
     }
+    // The reference samples by default (-t 1.0, -p 0.9; sampler.hpp:31-80, seeded from the clock).  This build decodes
+    // greedily only, and never silently: a request with a temperature is an error unless --greedy says it is meant.
     for (const RequestSpec &r : requests)
         if (r.temperature != 0.0f) {
-            fprintf(stderr, "[WARN] temperature %.2f asked; sampling here is greedy (temperature 0)\n", r.temperature);
+            if (!greedy) {
+                fprintf(stderr,
+                        "[ERROR] temperature %.2f asked: this build has no sampler (greedy decoding only).  Pass -t 0, or "
+                        "--greedy to decode every request greedily whatever it asks for\n",
+                        r.temperature);
+                return 2;
+            }
+            fprintf(stderr, "[WARN] temperature %.2f asked; --greedy: decoding with temperature 0\n", r.temperature);
             break;
         }
 
