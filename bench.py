@@ -245,6 +245,8 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed launches of the same step for about this long before the W warm-up steps, so that the "
                          "clocks have reached their steady state when the timed region starts (0 = off)")
+    ap.add_argument("--no-pairs", action="store_true",
+                    help="diagnostic: rows of 64 / 192 B one kv-head per wave (NVK_DECODE_NO_PAIRS)")
     ap.add_argument("--no-extra", action="store_true",
                     help="N=1 only: skip the extra BASELINE configs (3, 4, 5a, 5b) timed after the headline workload")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -288,6 +290,8 @@ def main():
                              work.block_tables[mine], False)
     flags = {"auto": nv.AUTO, "single": nv.SINGLE_PASS, "split": nv.SPLIT_K}[args.mode]
     flags |= {"auto": 0, "kernel": nv.MERGE_IN_KERNEL, "separate": nv.MERGE_SEPARATE}[args.merge]
+    if args.no_pairs:
+        flags |= nv.NO_PAIRS
     uniform_batch = bool((work.ctx_lens == work.ctx_lens[0]).all())
     if args.plan == "none" or (args.plan == "auto" and uniform_batch):
         flags |= nv.UNIFORM if uniform_batch else nv.NO_PLAN

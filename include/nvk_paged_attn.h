@@ -55,6 +55,12 @@ extern "C" {
 /* GQA groups of 5..16 q-heads over head_dim 64 / 128 run their dot products on fp32 MFMA tiles (exact fp32, another
  * order of sums than the vector kernel).  This modifier keeps such a launch on the vector kernel (A/B, tests). */
 #define NVK_DECODE_VECTOR_ONLY 0x1000
+/* Rows of 64 or 192 B (head_dim 16 / 48: the reference's own stories15M geometry, include/core/attention.hpp:114-115
+ * fixes the row at head_dim floats) share their 128-B lines with the neighbour kv-head; with an even number of
+ * kv-heads one wave streams a PAIR of heads -- whole lines, each read once.  Same arithmetic per head (tokens meet
+ * in another order: same tolerance, not the same bits).  This modifier keeps such a launch on one head per wave
+ * (A/B, tests). */
+#define NVK_DECODE_NO_PAIRS 0x2000
 
 /* prefill flags */
 #define NVK_PREFILL_AUTO 0    /* library picks by chunk length                                      */

@@ -27,6 +27,7 @@ MERGE_SEPARATE = _capi.DECODE_MERGE_SEPARATE
 UNIFORM = _capi.DECODE_UNIFORM
 NO_PLAN = _capi.DECODE_NO_PLAN
 VECTOR_ONLY = _capi.DECODE_VECTOR_ONLY
+NO_PAIRS = _capi.DECODE_NO_PAIRS
 
 
 def bind_pool(pool: Optional[PagedKVPool], layer: int = 0) -> None:

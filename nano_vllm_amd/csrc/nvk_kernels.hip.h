@@ -336,7 +336,7 @@ __device__ __forceinline__ void merge_chunks(const float *ws_o, const float *ws_
 // stale lines), its wait, a barrier, then plain loads.  Nobody waits for anybody: no spin, no residency
 // assumption, any placement of the chunks over XCDs.  qpk = q-heads per kv-head wave of this launch.
 __device__ __forceinline__ void combine_if_last(const DecodeParams &p, int *s_flag, int seq, int nch, int kvg, int zq,
-                                                int qsplit, int qpk)
+                                                int qsplit, int qpk, int kpw = 1)
 {
     NVK_STAMP(3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -359,10 +359,11 @@ __device__ __forceinline__ void combine_if_last(const DecodeParams &p, int *s_fl
     if (!s_flag[0])
         return;
     const int hd = p.head_dim, vec_row = hd >> 2;
-    const int n_mine = p.kv_waves * qpk * vec_row; // (q-head, float4) pairs of this workgroup's heads
+    const int kv_wg  = p.kv_waves * kpw;      // kv-heads of this workgroup's group
+    const int n_mine = kv_wg * qpk * vec_row; // (q-head, float4) pairs of this workgroup's heads
     for (int idx = threadIdx.x; idx < n_mine; idx += blockDim.x) {
         const int hh = idx / vec_row, vec = idx - hh * vec_row;
-        const int w = hh / qpk, kvh_w = kvg * p.kv_waves + w;
+        const int w = hh / qpk, kvh_w = kvg * kv_wg + w;
         if (kvh_w < p.n_kv_heads)
             merge_chunks(p.ws_o, p.ws_ml, p.out, seq, kvh_w * p.kv_mul + zq * qpk + (hh - w * qpk), vec, nch, p.n_heads,
                          hd, p.max_chunks);
@@ -374,18 +375,23 @@ __device__ __forceinline__ void combine_if_last(const DecodeParams &p, int *s_fl
 // VPL   float4 per lane per row (head_dim <= 64*VPL)
 // QPK   q-heads handled per kv-head by one wave (divides kv_mul; blockIdx.y also walks kv_mul/QPK)
 // FULL  head_dim == 64*VPL, so no lane is idle and no load needs a predicate
+// KPW   kv-heads per wave.  2 only for rows that are an odd number of 64-B half-lines (head_dim 16 / 48: a 192-B row
+//       shares a 128-B line with its neighbour kv-head): the wave's four 16-lane rows are then 2 tokens x 2 ADJACENT
+//       kv-heads, so one load instruction covers 2 * head_dim * 4 contiguous bytes = whole lines per token, every line
+//       is requested once (by one wave), and the loads can carry the read-once hint again.
 // grid: 1-D over (work item, kv-head group x q sub-group); workgroups past *n_items leave
 // Waves: wave w owns kv-head (w % kv_waves) of the group; when the pool has fewer than 8 kv-heads
 // (a head-sharded rank, small models; fewer than 4 for 256-float rows) the remaining waves split the
 // chunk's tokens ("token-split"):
 // wave w takes sub-range w / kv_waves, and the sub-ranges are merged through LDS at the end, so a
 // workgroup keeps 8 waves of loads in flight whatever the head count.
-template <int VPL, int QPK, bool FULL>
-__global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_PER_EU)
-    nvk_decode_kernel(const DecodeParams p)
+template <int VPL, int QPK, bool FULL, int KPW> __device__ __forceinline__ void decode_body(const DecodeParams &p)
 {
-    constexpr int kTokPerLane = tok_per_lane(VPL, QPK); // tokens each lane holds per step
-    constexpr int kStepTokens = step_tokens(VPL, QPK);  // tokens per wave per pipeline step
+    static_assert(KPW == 1 || (KPW == 2 && VPL == 1 && !FULL), "kv-head pairs are for short odd rows only");
+    constexpr int  kTokPerLane = tok_per_lane(VPL, QPK);       // tokens each lane holds per step
+    constexpr int  kSlots      = 4 / KPW;                      // token slots of a wave (16-lane rows per kv-head)
+    constexpr int  kStepTokens = step_tokens(VPL, QPK) / KPW;  // tokens per wave per pipeline step
+    constexpr bool kStream     = FULL || KPW == 2;             // row pieces are whole lines: read-once hint
     using Tile                = KVTile<VPL, kTokPerLane>;
     extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice (+ merge area)
 
@@ -426,14 +432,15 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
     const int lane   = threadIdx.x & 63;
     const int wave   = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int slot   = lane >> 4; // which token of a quad
-    const int r      = lane & 15; // which 16 B of a 256-B row piece
+    const int slot   = (lane >> 4) / KPW; // which token of a step's quad (pair)
+    const int hsub   = (lane >> 4) % KPW; // which kv-head of the wave's pair
+    const int r      = lane & 15;         // which 16 B of a 256-B row piece
 
     // waves enumerate the kv-heads of the group (and, with fewer kv-heads than waves, the token parts)
     const int  parts  = nwaves / p.kv_waves; // token-split factor (1 when the group has 8 kv-heads)
     const int  part   = wave / p.kv_waves;
-    const int  kvh    = kvg * p.kv_waves + wave % p.kv_waves;
-    const bool live   = kvh < p.n_kv_heads;
+    const int  kvh    = (kvg * p.kv_waves + wave % p.kv_waves) * KPW + hsub;
+    const bool live   = kvh < p.n_kv_heads; // (KPW == 2: per 16-lane row; an odd head count leaves the last row dead)
     const int  qh0    = kvh * p.kv_mul + zq * QPK; // first q-head of this wave
 
     const int hd = p.head_dim;
@@ -494,7 +501,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
     // split-K combine in this kernel: every wave of the workgroup stays to the end (the arrival protocol has
     // two barriers); otherwise waves without a kv-head leave now (they exist only when parts == 1: no barrier follows)
     const bool fused = p.arrivals != nullptr && nch > 1;
-    if (!live && !fused)
+    if (KPW == 1 && !live && !fused)
         return;
 
     // this wave's share of the chunk: whole steps
@@ -534,7 +541,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++) {
             // lanes past the chunk's end (last step only) re-read its last row; consume_tile masks their scores
-            const int tok = min(ts + 4 * i + slot, w1 - 1);
+            const int tok = min(ts + kSlots * i + slot, w1 - 1);
             const int blk = token_block(tok, p.bs_magic);
             const int off = token_offset(tok, blk, p.block_size);
             const int pb  = s_tab[blk - blk0];
@@ -546,7 +553,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
             for (int j = 0; j < VPL; j++) {
                 T.k[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act[j])
-                    T.k[i][j] = load_kv<FULL>(p.k_layer + at[i] + 64 * j);
+                    T.k[i][j] = load_kv<kStream>(p.k_layer + at[i] + 64 * j);
             }
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++)
@@ -554,7 +561,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
             for (int j = 0; j < VPL; j++) {
                 T.v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act[j])
-                    T.v[i][j] = load_kv<FULL>(p.v_layer + at[i] + 64 * j);
+                    T.v[i][j] = load_kv<kStream>(p.v_layer + at[i] + 64 * j);
             }
     };
 
@@ -564,7 +571,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
         float          s[kTokPerLane][QPK];
 #pragma unroll
         for (int i = 0; i < kTokPerLane; i++) {
-            const bool in_range = !TAIL || (ts + 4 * i + slot < w1);
+            const bool in_range = !TAIL || (ts + kSlots * i + slot < w1);
 #pragma unroll
             for (int h = 0; h < QPK; h++) {
                 float acc = 0.f;
@@ -636,14 +643,18 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
 
     NVK_STAMP(2)
     NVK_STAMP_WAVE()
-    // merge the four token slots of the wave (lanes 16 and 32 apart)
+    // merge the token slots of the wave (lanes 16 and 32 apart; with a kv-head pair per wave the rows 16 apart are
+    // the other head's, and only the rows 32 apart meet)
 #pragma unroll
     for (int h = 0; h < QPK; h++) {
-        float mw = fmaxf(m[h], __shfl_xor(m[h], 16));
-        mw       = fmaxf(mw, __shfl_xor(mw, 32));
+        float mw = m[h];
+        if (KPW == 1)
+            mw = fmaxf(mw, __shfl_xor(mw, 16));
+        mw            = fmaxf(mw, __shfl_xor(mw, 32));
         const float f = fast_exp2(m[h] - mw);
         float       lw = l[h] * f;
-        lw += __shfl_xor(lw, 16);
+        if (KPW == 1)
+            lw += __shfl_xor(lw, 16);
         lw += __shfl_xor(lw, 32);
         m[h] = mw;
         l[h] = lw;
@@ -651,8 +662,9 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
         for (int j = 0; j < VPL; j++) {
             float4 a = o[h][j];
             a.x *= f, a.y *= f, a.z *= f, a.w *= f;
-            a.x += __shfl_xor(a.x, 16), a.y += __shfl_xor(a.y, 16), a.z += __shfl_xor(a.z, 16),
-                a.w += __shfl_xor(a.w, 16);
+            if (KPW == 1)
+                a.x += __shfl_xor(a.x, 16), a.y += __shfl_xor(a.y, 16), a.z += __shfl_xor(a.z, 16),
+                    a.w += __shfl_xor(a.w, 16);
             a.x += __shfl_xor(a.x, 32), a.y += __shfl_xor(a.y, 32), a.z += __shfl_xor(a.z, 32),
                 a.w += __shfl_xor(a.w, 32);
             o[h][j] = a;
@@ -666,7 +678,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
         if (slot == 0 && part > 0) {
 #pragma unroll
             for (int h = 0; h < QPK; h++) {
-                float *rec = s_mrg + (wave * QPK + h) * kRec;
+                float *rec = s_mrg + ((wave * KPW + hsub) * QPK + h) * kRec;
                 if (r == 0)
                     rec[0] = m[h], rec[1] = l[h];
 #pragma unroll
@@ -682,7 +694,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
             for (int h = 0; h < QPK; h++) {
                 float mw = m[h];
                 for (int q = 1; q < parts; q++)
-                    mw = fmaxf(mw, s_mrg[((q * p.kv_waves + wave) * QPK + h) * kRec]);
+                    mw = fmaxf(mw, s_mrg[(((q * p.kv_waves + wave) * KPW + hsub) * QPK + h) * kRec]);
                 const float f0 = fast_exp2(m[h] - mw);
                 float       lw = l[h] * f0;
                 float4      a[VPL];
@@ -690,7 +702,7 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
                 for (int j = 0; j < VPL; j++)
                     a[j] = make_float4(o[h][j].x * f0, o[h][j].y * f0, o[h][j].z * f0, o[h][j].w * f0);
                 for (int q = 1; q < parts; q++) {
-                    const float *rec = s_mrg + ((q * p.kv_waves + wave) * QPK + h) * kRec;
+                    const float *rec = s_mrg + (((q * p.kv_waves + wave) * KPW + hsub) * QPK + h) * kRec;
                     const float  f   = fast_exp2(rec[0] - mw);
                     lw               = fmaf(rec[1], f, lw);
 #pragma unroll
@@ -755,7 +767,22 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
     if (!fused)
         return;
 
-    combine_if_last(p, s_tab, seq, nch, kvg, zq, qsplit, QPK);
+    combine_if_last(p, s_tab, seq, nch, kvg, zq, qsplit, QPK, KPW);
+}
+
+template <int VPL, int QPK, bool FULL>
+__global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_PER_EU)
+    nvk_decode_kernel(const DecodeParams p)
+{
+    decode_body<VPL, QPK, FULL, 1>(p);
+}
+
+// rows of 64 / 192 B (head_dim 16 / 48), an even number of kv-heads: a pair of adjacent kv-heads per wave (KPW = 2)
+template <int QPK>
+__global__ void __launch_bounds__(64 * wg_waves(1, QPK, false), NVK_MIN_WAVES_PER_EU)
+    nvk_decode_pairs_kernel(const DecodeParams p)
+{
+    decode_body<1, QPK, false, 2>(p);
 }
 
 // ---- the decode kernel on fp32 MFMA tiles, for GQA groups of 5..16 q-heads --------------------------------

@@ -43,6 +43,9 @@
 #ifndef NVK_MFMA_MIN_KVMUL
 #define NVK_MFMA_MIN_KVMUL 5 // q-heads per kv-head from which decode runs on fp32 MFMA tiles (head_dim 64 or 128, <= 16 heads)
 #endif
+#ifndef NVK_KV_PAIRS
+#define NVK_KV_PAIRS 1 // 1: rows of 64 / 192 B are streamed a pair of adjacent kv-heads per wave (whole lines)
+#endif
 #ifndef NVK_FUSE_MAX_CHUNKS
 #define NVK_FUSE_MAX_CHUNKS 16 // chunks per sequence up to which the split-K combine runs inside the decode kernel (the
                                // workgroup that completes a sequence merges it: one CU's worth of reading, fine for a
@@ -264,6 +267,7 @@ struct LaunchShape
     int vpl          = 1;
     bool full        = false;
     bool mfma        = false; // nvk_decode_mfma_kernel: one wave carries the whole GQA group on 16-token MFMA tiles
+    int  kpw         = 1;     // kv-heads per wave: 2 where a row is an odd number of half-lines (head_dim 16 / 48)
     size_t lds_bytes = 0;
     int  qgroups     = 1;     // (kv-head group, q sub-group) pairs per item = arrival counters per row
     bool fuse_merge  = false; // max_chunks > 1: the decode kernel combines a row's chunks itself
@@ -277,7 +281,7 @@ bool decode_flags_ok(int flags)
     if (mode != NVK_DECODE_AUTO && mode != NVK_DECODE_SINGLE_PASS && mode != NVK_DECODE_SPLIT_K)
         return false;
     if (mods & ~(NVK_DECODE_MERGE_IN_KERNEL | NVK_DECODE_MERGE_SEPARATE | NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN
-                 | NVK_DECODE_VECTOR_ONLY))
+                 | NVK_DECODE_VECTOR_ONLY | NVK_DECODE_NO_PAIRS))
         return false;
     return !((mods & NVK_DECODE_MERGE_IN_KERNEL) && (mods & NVK_DECODE_MERGE_SEPARATE));
 }
@@ -312,13 +316,20 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     if (plan->mfma)
         plan->qpk = kv_mul;
     const int wg_waves = plan->mfma ? 8 : std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl, plan->qpk, plan->full));
-    plan->waves      = std::min(pool->n_kv_heads, wg_waves);
-    plan->kv_groups  = (pool->n_kv_heads + plan->waves - 1) / plan->waves;
+    // rows of 64 or 192 B (head_dim 16 / 48) share their 128-B lines with the neighbour kv-head: a wave then takes
+    // the PAIR of heads (whole lines per token, each requested once); needs token rows that start on a line
+    plan->kpw = (NVK_KV_PAIRS && plan->vpl == 1 && hd % 32 == 16 && pool->n_kv_heads % 2 == 0 && plan->qpk <= 4
+                 && !(mods & NVK_DECODE_NO_PAIRS))
+                    ? 2
+                    : 1;
+    const int kv_slots = pool->n_kv_heads / plan->kpw; // waves along the kv axis in all
+    plan->waves      = std::min(kv_slots, wg_waves);
+    plan->kv_groups  = (kv_slots + plan->waves - 1) / plan->waves;
     // fewer kv-heads than a workgroup has waves (a head-sharded rank, a small model): the other waves split
     // the chunk's tokens, so the workgroup still has all its waves' loads in flight
     plan->parts      = plan->kv_groups == 1 ? std::max(1, wg_waves / plan->waves) : 1;
 
-    const int step    = plan->mfma ? 16 : nvk::step_tokens(plan->vpl, plan->qpk);
+    const int step    = plan->mfma ? 16 : nvk::step_tokens(plan->vpl, plan->qpk) / plan->kpw;
     const int ctx_cap = round_up(std::max(max_ctx, 1), step);
     // a workgroup stages its chunk's table slice in LDS: bound the chunk by that
     const long long slice_cap = (long long)kMaxTableSliceEntries * pool->block_size / step * step;
@@ -362,7 +373,7 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     plan->merge_off    = (plan->chunk_tokens / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
     plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int);
     if (plan->parts > 1)
-        plan->lds_bytes += (size_t)plan->waves * plan->parts * plan->qpk * (4 + plan->vpl * 64) * sizeof(float);
+        plan->lds_bytes += (size_t)plan->waves * plan->parts * plan->kpw * plan->qpk * (4 + plan->vpl * 64) * sizeof(float);
     plan->qgroups            = plan->kv_groups * (kv_mul / plan->qpk);
     plan->force_serial_merge = (mods & NVK_DECODE_MERGE_SEPARATE) != 0;
     plan->fuse_merge         = plan->max_chunks > 1 && !plan->force_serial_merge
@@ -401,6 +412,15 @@ template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, d
 
 hipError_t launch_decode(const LaunchShape &plan, dim3 grid, dim3 block, hipStream_t stream, const nvk::DecodeParams &p)
 {
+    if (plan.kpw == 2) { // make_shape: vpl 1, not full, at most 4 q-heads per wave
+        switch (plan.qpk) {
+        case 4: hipLaunchKernelGGL((nvk::nvk_decode_pairs_kernel<4>), grid, block, plan.lds_bytes, stream, p); break;
+        case 3: hipLaunchKernelGGL((nvk::nvk_decode_pairs_kernel<3>), grid, block, plan.lds_bytes, stream, p); break;
+        case 2: hipLaunchKernelGGL((nvk::nvk_decode_pairs_kernel<2>), grid, block, plan.lds_bytes, stream, p); break;
+        default: hipLaunchKernelGGL((nvk::nvk_decode_pairs_kernel<1>), grid, block, plan.lds_bytes, stream, p); break;
+        }
+        return hipGetLastError();
+    }
     if (plan.mfma) {
         if (plan.vpl == 1)
             hipLaunchKernelGGL((nvk::nvk_decode_mfma_kernel<64>), grid, block, plan.lds_bytes, stream, p);
@@ -1826,6 +1846,8 @@ int nvk_decode_kernel_name(nvk_pool *pool, int num_seqs, int n_heads, int max_ct
         return rc;
     if (sh.mfma)
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_mfma_kernel<%d>", 64 * sh.vpl);
+    else if (sh.kpw == 2)
+        snprintf(buf, (size_t)cap, "nvk::nvk_decode_pairs_kernel<%d>", sh.qpk);
     else
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_kernel<%d, %d, %s>", sh.vpl, sh.qpk, sh.full ? "true" : "false");
     return NVK_OK;
