@@ -925,7 +925,15 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
 #else
 #pragma unroll
         for (int m = 0; m < NM; m++)
+#ifdef NVK_MFMA_K_NT // A/B: the read-once hint on K too
             T.k[m] = load_kv<true>(p.k_layer + atk + 16 * m);
+#else
+            // K arrives as 64-B half-lines (the A operand's shape): the instruction for the other half follows at
+            // once and should find the line in L1, which the read-once hint would have dropped.  Measured
+            // (profiles/r02_variants_mfma_k_hint.log): GQA-8 64 x 2K 0.72 -> 0.78 of peak, 512 x 2K 0.84 -> 0.85;
+            // head_dim 64: 0.70 -> 0.72 and 0.856 -> 0.846.  V (whole lines per instruction) keeps the hint.
+            T.k[m] = load_kv<false>(p.k_layer + atk + 16 * m);
+#endif
 #endif
 #pragma unroll
         for (int i = 0; i < 4; i++)
