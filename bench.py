@@ -67,6 +67,9 @@ def make_workload(name, rank=0, geom="llama"):
         return wl.Workload("decode_256xragged_contiguous", w.geom, int(need.sum()), w.ctx_lens, tabs)
     if name == "config2f":  # diagnostic: config 2's uniform lengths behind fragmented tables
         return wl.fragmented_workload("decode_64x2048_fragmented", np.full(64, 2048, np.int32))
+    if name.startswith("u") and "x" in name:  # diagnostic: uNxT = N sequences of T tokens behind fragmented tables
+        n, t = (int(v) for v in name[1:].split("x"))
+        return wl.fragmented_workload(f"decode_{n}x{t}_fragmented", np.full(n, t, np.int32))
     if name == "5a":
         return wl.config5a(512, first_seq=512 * rank)  # rank r's slice of the 4096-sequence batch
     if name == "5b":

@@ -67,3 +67,12 @@ for w in range(8):
     if ok.any():
         d = np.sort((s[ok, 8 + w] - s[ok, 1]) / 100.0)
         print(f"    wave {w}: min {d[0]:8.2f}  med {d[len(d)//2]:8.2f}  max {d[-1]:8.2f} us")
+ids = np.nonzero(live)[0]
+ok = s[:, 2] > 0
+print("  main loop (2 - 1) by workgroup id % 8 (XCD), median / max:")
+for x in range(8):
+    sel = ok & (ids % 8 == x)
+    if sel.any():
+        d = (s[sel, 2] - s[sel, 1]) / 100.0
+        print(f"    xcd {x}: n {sel.sum():4d}  med {np.median(d):8.2f}  max {d.max():8.2f}   by id // 8 quartiles: "
+              + " ".join(f"{np.median(q):7.2f}" for q in np.array_split(d, 4)))
