@@ -122,6 +122,9 @@ struct DecodeParams
     // between launches; the workgroup whose arrival completes a sequence's chunks merges them (null: the partials
     // are left for nvk_merge_kernel / nvk_merge_wide_kernel).
     int            *arrivals;
+    // Uniform batches: workgroup i takes item (i % 8) * (n / 8) + i / 8 instead of item i, so that the workgroups of
+    // one XCD (ids go round-robin over the 8 XCDs) stream one contiguous eighth of the batch -- see xcd_range_item.
+    int             xcd_ranges;
 #ifdef NVK_STAMPS // diagnostic build: sixteen 100 MHz timestamps per workgroup (tools/wg_timeline.py)
     unsigned long long *stamps;
 #endif
@@ -182,6 +185,23 @@ template <bool NT> __device__ __forceinline__ float4 load_kv(const float *p)
     }
 #endif
     return *reinterpret_cast<const float4 *>(p);
+}
+
+// ---- which item a workgroup of a uniform batch takes ------------------------------------------------------
+// Workgroup ids go round-robin over the 8 XCDs.  With item = id, every XCD walks the whole batch at a stride of 8
+// items; behind contiguous block tables that is 8 address streams 8 chunks apart per XCD, and how fast they run
+// then depends on where the pool happens to lie: config 4 at 0.75 or 0.86 of the HBM peak, 5b at 0.80 or 0.87,
+// by the distance between a layer's K slab and V slab alone (profiles/r02_sweep_pool_skew.log).  Dealing each XCD
+// one contiguous eighth of the items instead takes the lottery away (0.84-0.86 and 0.86-0.87 at every distance
+// tried, profiles/r02_sweep_item_order.log).  A bijection of [0, n) for any n: XCD x owns n / 8 (+1 for the
+// first n % 8) consecutive items.  Only for batches of equal lengths: ragged ones are dealt longest-first by the
+// plan, round-robin, which is what balances the XCDs.  Every item is computed as before: same bits.
+__device__ __forceinline__ int xcd_range_item(int id, int n, int enabled)
+{
+    if (!enabled)
+        return id;
+    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+    return x * q + min(x, r) + k;
 }
 
 // ---- the plan kernel: context lengths -> work items, longest first ----------
@@ -413,6 +433,7 @@ template <int VPL, int QPK, bool FULL, int KPW> __device__ __forceinline__ void 
     if (p.direct) {
         if (item_i >= p.num_seqs * p.max_chunks)
             return;
+        item_i  = xcd_range_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges);
         seq     = item_i / p.max_chunks;
         chunk   = item_i - seq * p.max_chunks;
         t0      = chunk * p.chunk_tokens;
@@ -818,11 +839,12 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
 
     NVK_STAMP(0)
     const int kvg    = blockIdx.x / p.items_padded; // one wave carries the whole GQA group: no q sub-groups
-    const int item_i = blockIdx.x - kvg * p.items_padded;
+    int       item_i = blockIdx.x - kvg * p.items_padded;
     int seq, chunk, nch = 0, t0, t1 = 0, ctx_raw = 0;
     if (p.direct) {
         if (item_i >= p.num_seqs * p.max_chunks)
             return;
+        item_i  = xcd_range_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges);
         seq     = item_i / p.max_chunks;
         chunk   = item_i - seq * p.max_chunks;
         t0      = chunk * p.chunk_tokens;

@@ -43,6 +43,15 @@
 #ifndef NVK_MFMA_MIN_KVMUL
 #define NVK_MFMA_MIN_KVMUL 5 // q-heads per kv-head from which decode runs on fp32 MFMA tiles (head_dim 64 or 128, <= 16 heads)
 #endif
+#ifndef NVK_POOL_LAYOUT
+#define NVK_POOL_LAYOUT 1 // 1: one allocation, [layer][K slab | V slab]; 0: K pool and V pool, [layer][slab] each (A/B)
+#endif
+#ifndef NVK_XCD_RANGES
+#define NVK_XCD_RANGES 1 // 1: uniform batches deal each XCD a contiguous eighth of the items (xcd_range_item)
+#endif
+#ifndef NVK_POOL_SKEW_BYTES
+#define NVK_POOL_SKEW_BYTES 0 // bytes of padding behind every slab of the one-allocation layout (a multiple of 256)
+#endif
 #ifndef NVK_KV_PAIRS
 #define NVK_KV_PAIRS 1 // 1: rows of 64 / 192 B are streamed a pair of adjacent kv-heads per wave (whole lines)
 #endif
@@ -97,6 +106,8 @@ struct nvk_pool
     unsigned bs_magic   = 0;
     size_t layer_floats = 0; // num_blocks * block_size * n_kv_heads * head_dim
     float *k = nullptr, *v = nullptr;
+    size_t layer_stride = 0; // floats from one layer's K (V) slab to the next layer's
+    bool   one_allocation = false; // NVK_POOL_LAYOUT 1: [layer][K slab | V slab] in one allocation (v = k + layer_floats)
     hipStream_t stream = nullptr;
     int         num_cus = 256;
 
@@ -132,8 +143,8 @@ struct nvk_pool
     float *rope_inv_freq = nullptr; // [head_dim / 2] on the device
     float  rope_theta    = 0.f;     // 0 = table not built
 
-    float *k_layer(int layer) const { return k + (size_t)layer * layer_floats; }
-    float *v_layer(int layer) const { return v + (size_t)layer * layer_floats; }
+    float *k_layer(int layer) const { return k + (size_t)layer * layer_stride; }
+    float *v_layer(int layer) const { return v + (size_t)layer * layer_stride; }
     int    row_len() const { return n_kv_heads * head_dim; }
 };
 
@@ -627,6 +638,13 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     p.uniform_ctx  = plan->uniform_ctx;
     p.ctx_lens     = plan->ctx_lens_dev;
     p.arrivals     = sh.fuse_merge ? ws.arrivals : nullptr;
+    // (only where a workgroup's waves are the kv-heads of whole token rows: with token-split waves -- a head-sharded
+    // rank's 512-B rows -- the same dealing measured 0.61-0.76 against 0.81, profiles/r02_sweep_item_order.log)
+    p.xcd_ranges = (NVK_XCD_RANGES && plan->direct && !plan->ctx_lens_dev && kv_mul == sh.qpk && sh.parts == 1) ? 1 : 0;
+#ifdef NVK_XCD_RANGES_ENV // A/B build
+    if (getenv("NVK_XCD_RANGES_OFF"))
+        p.xcd_ranges = 0;
+#endif
 #ifdef NVK_STAMPS
     p.stamps = g_debug_stamps;
 #endif
@@ -1083,9 +1101,35 @@ int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads
         pool->num_cus = prop.multiProcessorCount;
 
     const size_t bytes = pool->layer_floats * (size_t)n_layers * sizeof(float);
-    hipError_t   e     = hipMalloc(&pool->k, bytes);
-    if (e == hipSuccess)
-        e = hipMalloc(&pool->v, bytes);
+    // A layer-call streams the layer's K slab and V slab side by side.  Measured (profiles/r02_sweep_pool_layers_5b.log,
+    // r02_hbm_alloc_probe.log): two streams 16 GiB or more apart run at 0.79-0.80 of the HBM peak, two streams a slab
+    // apart at 0.87 -- so a layer's V slab sits right behind its K slab, [layer][K | V] in ONE allocation, instead of
+    // the reference's two arrays of [layer][slab] (model.hpp:95,262-265), in which a 32-layer pool puts them half the
+    // pool apart.  (Two allocations remain the fallback when one of twice the size cannot be had.)
+    hipError_t e = hipErrorOutOfMemory;
+#if NVK_POOL_LAYOUT == 1
+    size_t skew = NVK_POOL_SKEW_BYTES / sizeof(float); // floats between the end of a K slab and its V slab (and the next K)
+#ifdef NVK_POOL_SKEW_ENV // A/B build: the skew from the environment
+    if (const char *env = getenv("NVK_POOL_SKEW"))
+        skew = (size_t)atoll(env) / sizeof(float);
+#endif
+    e = hipMalloc(&pool->k, 2 * (bytes + (size_t)n_layers * skew * sizeof(float)));
+    if (e == hipSuccess) {
+        pool->one_allocation = true;
+        pool->layer_stride   = 2 * (pool->layer_floats + skew);
+        pool->v              = pool->k + pool->layer_floats + skew;
+    }
+    else {
+        (void)hipGetLastError();
+        pool->k = nullptr;
+    }
+#endif
+    if (!pool->one_allocation) {
+        pool->layer_stride = pool->layer_floats;
+        e                  = hipMalloc(&pool->k, bytes);
+        if (e == hipSuccess)
+            e = hipMalloc(&pool->v, bytes);
+    }
     if (e == hipSuccess)
         e = hipStreamCreateWithFlags(&pool->stream, hipStreamNonBlocking);
     if (e == hipSuccess)
@@ -1094,8 +1138,9 @@ int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads
         e = hipEventCreate(&pool->ev_b);
     // zero like std::vector::resize in initialize_paged_attention (model.hpp:267-268)
     if (e == hipSuccess)
-        e = hipMemsetAsync(pool->k, 0, bytes, pool->stream);
-    if (e == hipSuccess)
+        e = hipMemsetAsync(pool->k, 0, pool->one_allocation ? pool->layer_stride * (size_t)n_layers * sizeof(float) : bytes,
+                           pool->stream);
+    if (e == hipSuccess && !pool->one_allocation)
         e = hipMemsetAsync(pool->v, 0, bytes, pool->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(pool->stream);
@@ -1145,7 +1190,7 @@ int nvk_pool_destroy(nvk_pool *pool)
         (void)hipStreamSynchronize(pool->stream);
     if (pool->k)
         (void)hipFree(pool->k);
-    if (pool->v)
+    if (pool->v && !pool->one_allocation)
         (void)hipFree(pool->v);
     if (pool->ws_o)
         (void)hipFree(pool->ws_o);
