@@ -85,10 +85,12 @@ int nvk_device_count(void);
  * ref: Config paged fields        include/core/model.hpp:33-36
  *      RunState::paged_*_cache    include/core/model.hpp:94-97
  *      initialize_paged_attention include/core/model.hpp:249-277
- * Layout in HBM is the reference's, unchanged, so block tables built by a
+ * Inside a layer's K slab and V slab the layout is the reference's, unchanged, so block tables built by a
  * reference-equivalent BlockManager index it directly:
- *   K and V each [n_layers, num_blocks, block_size, n_kv_heads, head_dim] fp32.
- * Zero-initialised like the reference's std::vector::resize. */
+ *   one slab = [num_blocks, block_size, n_kv_heads, head_dim] fp32.
+ * Where the slabs lie is the library's business (one allocation, a layer's V slab right behind its K slab: the two
+ * streams of a layer-call run measurably faster side by side than half a pool apart); callers that need addresses
+ * ask nvk_pool_layer_ptrs per layer.  Zero-initialised like the reference's std::vector::resize. */
 int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads, int head_dim, int device,
                     nvk_pool **out_pool);
 int nvk_pool_destroy(nvk_pool *pool);
