@@ -170,3 +170,22 @@ def test_in_kernel_merge_at_full_size_under_load(name):
             assert same_bits(fused, apart), f"{name} round {rnd}"
             auto = decode_dev(pool, work, q, work.block_tables, work.ctx_lens, nv.AUTO)
             assert same_bits(auto, fused), f"{name}: the default launch is the in-kernel combine here"
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 15, 17, 63, 65, 130, 257])
+def test_uniform_batches_of_any_size_cover_every_item(n):
+    """Uniform batches deal each XCD a contiguous eighth of the items (xcd_range_item: workgroup w takes item
+    (w % 8) * n / 8 + w / 8, the first n % 8 ranges one longer).  Whatever n, every (sequence, chunk) must be taken
+    exactly once: rows pre-filled with NaN come back complete and bit-equal to the planned launch."""
+    g = wl.G_LLAMA
+    T = 200
+    ctx = np.full(n, T, np.int32)
+    work = wl.fragmented_workload(f"ranges{n}", ctx, g, perm_seed=n)
+    q = work.q()
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for mode, chunk in ((nv.SINGLE_PASS, 0), (nv.SPLIT_K, 48), (nv.SPLIT_K | nv.MERGE_SEPARATE, 64)):
+            planned = decode_dev(pool, work, q, work.block_tables, ctx, mode, chunk)
+            uniform = decode_dev(pool, work, q, work.block_tables, ctx, mode | nv.UNIFORM, chunk, max_ctx=T, ctx_dev=None)
+            assert np.isfinite(uniform).all(), f"n={n} mode 0x{mode:x}: an item was never computed"
+            assert same_bits(planned, uniform), f"n={n} mode 0x{mode:x}"
