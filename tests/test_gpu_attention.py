@@ -603,3 +603,34 @@ def test_two_pools_driven_from_two_host_threads():
     assert not errors, errors
     for tid, (got, want) in results.items():
         assert_close(got, want, f"thread {tid}")
+
+
+def test_layers_and_slabs_of_a_pool_do_not_overlap():
+    """The pool is one allocation, [layer][K slab | V slab] (the reference keeps two arrays of [layer][slab],
+    include/core/model.hpp:95,262-265; where the slabs lie is the library's business).  Every (layer, K/V, block)
+    is its own storage: distinct contents written to all of them come back unchanged, the per-layer addresses are
+    disjoint ranges of one slab each, and attention on one layer sees that layer's rows only."""
+    L, nb, bs, KV, hd, H = 3, 5, 4, 2, 16, 4
+    rng = np.random.default_rng(12)
+    blocks = rng.standard_normal((L, 2, nb, bs, KV, hd)).astype(np.float32)
+    slab = nb * bs * KV * hd * 4
+    with nv.PagedKVPool(L, nb, bs, KV, hd) as pool:
+        for layer in range(L):
+            for b in range(nb):
+                pool.upload_block(layer, b, blocks[layer, 0, b], blocks[layer, 1, b])
+        spans = []
+        for layer in range(L):
+            k_ptr, v_ptr = pool.layer_ptrs(layer)
+            spans += [(k_ptr, k_ptr + slab), (v_ptr, v_ptr + slab)]
+            for b in range(nb):
+                k, v = pool.download_block(layer, b)
+                assert np.array_equal(k, blocks[layer, 0, b]) and np.array_equal(v, blocks[layer, 1, b])
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), spans
+        q = rng.standard_normal((1, H, hd)).astype(np.float32)
+        table = np.arange(nb, dtype=np.int32)[None]
+        T = nb * bs - 1
+        for layer in range(L):
+            want = ol.oracle_paged_attention(q[0], blocks[layer, 0], blocks[layer, 1], table[0], T, bs, hd, H, KV)
+            got = nv.decode(pool, layer, q, table, np.array([T], np.int32), nv.AUTO)[0]
+            assert_close(got, want, f"layer {layer}")
