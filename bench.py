@@ -216,6 +216,208 @@ def extra_workloads(nv, torch, dev, args):
     return res
 
 
+class Watchdog:
+    """Bounds the N>1 extras: if they are not finished after `seconds` (a rank stuck in a collective, say), rank 0
+    prints the headline line with what the extras have so far and every rank's process ends with status 0."""
+
+    def __init__(self, seconds, rank, line, partial):
+        import threading
+
+        self._lock = threading.Lock()
+        self._state = "running"
+        self._done = threading.Event()
+
+        def dog():
+            if self._done.wait(seconds):
+                return
+            with self._lock:
+                if self._state != "running":
+                    return
+                self._state = "timed out"
+            if line is not None:
+                got = dict(partial)
+                got["error"] = f"extras not finished after {seconds:.0f} s on rank {rank}: line printed without the rest"
+                line["multi_gpu_workloads"] = got
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=dog, daemon=True).start()
+
+    def finish(self):
+        """True: the extras came back in time and the caller prints; False: the watchdog has taken over."""
+        with self._lock:
+            if self._state != "running":
+                return False
+            self._state = "finished"
+        self._done.set()
+        return True
+
+
+def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red_dev, barrier, res):
+    """BASELINE.json configs[4] across the ranks of this launch; fills `res` key by key (all ranks; rank 0's is printed).
+
+    5a / 5b: rank r decodes sequences [512 r, 512 (r + 1)) of the 512 x world from a pool of its own: weak scaling, no
+    collective, GB/s and tokens/s = all ranks' work over the slowest rank's wall time between two barriers.
+    5b_head_sharded: ONE batch of 512 x world sequences, rank r holding kv-heads [r KV / world, (r + 1) KV / world) of
+    every sequence (the same bytes per GPU as 5b), out joined by one all-gather per layer-call inside the timed region."""
+    from nano_vllm_amd import sharding as sh
+    from nano_vllm_amd import workloads as wl
+
+    steps = 10
+
+    def reduce_max(*vals):
+        t = torch.tensor(list(vals), dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    def device_inputs(work):
+        q = torch.from_numpy(work.q()).to(dev)
+        tabs = torch.from_numpy(work.block_tables).to(dev)
+        ctx = torch.from_numpy(work.ctx_lens).to(dev)
+        return q, tabs, ctx, torch.empty_like(q)
+
+    for name in ("5a", "5b"):
+        work = make_workload(name, rank)
+        g = work.geom
+        uniform_batch = bool((work.ctx_lens == work.ctx_lens[0]).all())
+        flags = nv.AUTO | (nv.UNIFORM if uniform_batch else 0)
+        with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=local_rank) as pool:
+            pool.fill_uniform(0, 1 + 16 * rank, 2 + 16 * rank)
+            q, tabs, ctx, out = device_inputs(work)
+            torch.cuda.synchronize()
+
+            def run(warmup, iters, want_attn):
+                return nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
+                                       out, flags, 0, warmup, iters, replan_every=1, want_attn=want_attn)
+
+            est_ms, _ = run(3, 3, False)
+            run(min(2000, int(args.prewarm_ms / max(est_ms, 1e-3)) + 1), 0, False)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            run(0, steps, False)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            barrier()
+            _, attn_ms = run(0, steps, True)
+            # every rank's batch has its own lengths (5a): the job's bytes are the sum over ranks
+            tot = torch.tensor([float(work.algorithmic_bytes()), float(work.num_seqs)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            wall, attn_ms = reduce_max(wall, attn_ms)
+            ms = wall * 1e3 / steps
+            res[name] = {"workload": f"{work.name} per GPU x {world} GPUs, sequence-sharded, no collective",
+                         "scaling": "weak", "steps": steps, "ms_per_step": round(ms, 4),
+                         "GBps": round(float(tot[0]) / (ms * 1e-3) / 1e9, 1),
+                         "frac_per_gpu": round(float(tot[0]) / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "slowest_kernel_ms": round(attn_ms, 4), "sequences": int(tot[1]),
+                         "tokens_per_s": round(float(tot[1]) / (ms * 1e-3), 1)}
+            del q, tabs, ctx, out
+        torch.cuda.empty_cache()
+
+    full = wl.config5b(512 * world)
+    gf = full.geom
+    if gf.n_kv_heads % world != 0:
+        res["5b_head_sharded"] = {"skipped": f"{world} ranks do not divide {gf.n_kv_heads} kv-heads"}
+        return
+    hs = sh.HeadShard(rank, world, gf.n_heads, gf.n_kv_heads)
+    g = wl.Geometry(hs.local_heads, hs.local_kv_heads, gf.head_dim, gf.block_size)
+    work = wl.Workload(full.name + f"_heads{rank}of{world}", g, full.num_blocks, full.ctx_lens, full.block_tables, False)
+    flags = nv.AUTO | nv.UNIFORM
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=local_rank) as pool:
+        pool.fill_uniform(0, 1 + 16 * rank, 2 + 16 * rank)
+        q, tabs, ctx, out = device_inputs(work)
+        torch.cuda.synchronize()
+        wall, step_ms, attn_ms = head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, 0, steps, 3,
+                                                  args.backend, rank, world, local_rank, dev, barrier)
+        wall, step_ms, attn_ms = reduce_max(wall, step_ms, attn_ms)
+        ms = wall * 1e3 / steps
+        nbytes = work.algorithmic_bytes()  # this rank's heads of the whole batch
+        shard_bytes = work.num_seqs * g.n_heads * g.head_dim * 4
+        res["5b_head_sharded"] = {
+            "workload": f"{full.name}: ONE batch, {g.n_kv_heads} of {gf.n_kv_heads} kv-heads per GPU x {world} GPUs",
+            "scaling": "weak in bytes per GPU (the batch grows with the GPUs, the heads per GPU shrink)",
+            "collective": ("ncclAllGather (RCCL) through nvk_shard_*, on its own stream under the next layer-call"
+                           if args.backend == "nccl" else "gloo on host copies: rehearsal"),
+            "gather_bytes_per_rank": {"sent": shard_bytes, "gathered": shard_bytes * world},
+            "steps": steps, "ms_per_step": round(ms, 4), "event_ms_per_step": round(step_ms, 4),
+            "GBps": round(nbytes * world / (ms * 1e-3) / 1e9, 1),
+            "frac_per_gpu": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "slowest_kernel_ms": round(attn_ms, 4), "sequences": work.num_seqs,
+            "tokens_per_s": round(work.num_seqs / (ms * 1e-3), 1)}
+        del q, tabs, ctx, out
+    torch.cuda.empty_cache()
+
+
+def head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, chunk, steps, warmup, backend, rank, world,
+                     local_rank, dev, barrier):
+    """K x (attention of this rank's heads, then ONE all-gather of out): (wall s, event ms per step, kernel ms).
+
+    With RCCL the gather goes through the library's own C ABI (nvk_shard_*: ncclAllGather called directly, on a
+    communication stream behind an event) and is overlapped: layer-call i's gather runs under layer-call i + 1's
+    attention, two (out, gathered) buffer pairs in turn, the consumer of gathered[i] waiting one step behind -- as the
+    wo projection of a model's layer would.  With gloo (rehearsal: ranks share a GPU, which RCCL refuses) the
+    collective runs on host copies through torch.distributed, not overlapped."""
+    from nano_vllm_amd import sharding as sh
+
+    g = work.geom
+    side = torch.cuda.Stream(device=dev)
+    prev_stream = torch.cuda.current_stream(dev)
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0  # (the C ABI reads a NULL stream as "the pool's own stream")
+    outs = [out, torch.empty_like(out)]
+    gath = [torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev) for _ in range(2)]
+    shard = None
+    try:
+        if backend == "nccl":
+            ids = [sh.NvkShard.new_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            shard = sh.NvkShard(rank, world, ids[0], local_rank, hs.n_heads, hs.n_kv_heads)
+
+        def step(i):
+            b = i % 2
+            if shard is not None:
+                shard.decode_gather(pool, 0, work.num_seqs, q, tabs, work.max_blocks, ctx, work.max_ctx, outs[b],
+                                    gath[b], b, flags, chunk, compute_stream=stream)
+                if i > 0:
+                    shard.wait_gather(1 - b, stream)  # the consumer of the previous layer-call's rows
+            else:
+                nv.decode_device(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
+                                 outs[b], flags, chunk, stream=stream)
+                gath[b].copy_(hs.all_gather_out(outs[b].cpu()))
+
+        def drain(i):
+            if shard is not None and i > 0:
+                shard.wait_gather((i - 1) % 2, stream)
+
+        for i in range(warmup):
+            step(i)
+        drain(warmup)
+        torch.cuda.synchronize()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            step(i)
+        drain(steps)
+        ev1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        barrier()
+        step_ms = ev0.elapsed_time(ev1) / steps
+        # the attention kernel alone in this rank's shape, HIP events on the pool's stream
+        _, attn_ms = nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx, out,
+                                     flags, chunk, 2, 16, replan_every=1, want_attn=True, rotate_layers=1)
+        torch.cuda.synchronize()
+    finally:
+        if shard is not None:
+            shard.close()
+        torch.cuda.set_stream(prev_stream)
+    return wall, step_ms, attn_ms
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +456,9 @@ def main():
                     help="diagnostic: rows of 64 / 192 B one kv-head per wave (NVK_DECODE_NO_PAIRS)")
     ap.add_argument("--no-extra", action="store_true",
                     help="N=1 only: skip the extra BASELINE configs (3, 4, 5a, 5b) timed after the headline workload")
+    ap.add_argument("--extra-timeout", type=float, default=150.0,
+                    help="N>1 only: seconds the configs[4] extras (5a / 5b sequence-sharded, 5b head-sharded) may take "
+                         "before the headline line is printed without them")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no per-kernel event pairs inside the timed region (roofline from step time)")
     args = ap.parse_args()
@@ -360,67 +565,16 @@ def main():
             rotated = (r_step, r_attn)
         torch.cuda.synchronize()
     else:
-        # K x (attention of this rank's heads, then ONE all-gather of out).  With RCCL the gather goes through the
-        # library's own C ABI (nvk_shard_*: ncclAllGather called directly, on a communication stream behind an event)
-        # and is overlapped: layer-call i's gather runs under layer-call i + 1's attention, two (out, gathered)
-        # buffer pairs in turn, the consumer of gathered[i] waiting one step behind -- as the wo projection of a
-        # model's layer would.  With gloo (rehearsal: ranks share a GPU, which RCCL refuses) the collective runs on
-        # host copies through torch.distributed, not overlapped.
-        side = torch.cuda.Stream(device=dev)
-        torch.cuda.set_stream(side)
-        stream = side.cuda_stream
-        assert stream != 0  # (the C ABI reads a NULL stream as "the pool's own stream")
-        outs = [out, torch.empty_like(out)]
-        gath = [torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev) for _ in range(2)]
-        shard = None
-        if args.backend == "nccl":
-            ids = [sh.NvkShard.new_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            shard = sh.NvkShard(rank, world, ids[0], local_rank, hs.n_heads, hs.n_kv_heads)
-
-        def step(i):
-            b = i % 2
-            if shard is not None:
-                shard.decode_gather(pool, 0, work.num_seqs, q, tabs, work.max_blocks, ctx, work.max_ctx, outs[b],
-                                    gath[b], b, flags, args.chunk, compute_stream=stream)
-                if i > 0:
-                    shard.wait_gather(1 - b, stream)  # the consumer of the previous layer-call's rows
-            else:
-                nv.decode_device(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
-                                 outs[b], flags, args.chunk, stream=stream)
-                gath[b].copy_(hs.all_gather_out(outs[b].cpu()))
-
-        def drain(i):
-            if shard is not None and i > 0:
-                shard.wait_gather((i - 1) % 2, stream)
-
-        for i in range(args.warmup):
-            step(i)
-        drain(args.warmup)
-        torch.cuda.synchronize()
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for i in range(args.steps):
-            step(i)
-        drain(args.steps)
-        ev1.record()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        barrier()
-        step_ms = ev0.elapsed_time(ev1) / args.steps
-        _, attn_ms = run(2, 16, True)  # the attention kernel alone in this rank's shape, HIP events on the pool's stream
-        torch.cuda.synchronize()
-        if shard is not None:
-            shard.close()
+        wall, step_ms, attn_ms = head_sharded_leg(nv, torch, dist if world > 1 else None, hs, pool, work, q, tabs, ctx, out,
+                                                  flags, args.chunk, args.steps, args.warmup, args.backend, rank, world,
+                                                  local_rank, dev, barrier)
 
     if world > 1:
         t = torch.tensor([wall, step_ms, attn_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, step_ms, attn_ms = (float(x) for x in t.tolist())
 
+    line = None
     if rank == 0:
         nbytes = work.algorithmic_bytes()  # per rank, per layer-call
         ms_per_step = wall * 1e3 / args.steps
@@ -481,12 +635,40 @@ def main():
                 line["cpu_baseline"] = one
             if many is not None:
                 line["cpu_baseline_all_cores"] = many
+
+    # N > 1, default launch: BASELINE.json configs[4] while all ranks are here -- 5a and 5b sequence-sharded (rank r's
+    # 512 of the 512 x N sequences, no collective) and 5b's batch head-sharded (every rank a kv-head group of ALL
+    # 512 x N sequences, one RCCL all-gather of out per layer-call through nvk_shard_*).  Extra keys of the same line;
+    # a watchdog prints the headline without them if a rank fails to come back.
+    multi = None
+    if (world > 1 and args.shard == "seq" and not args.strong and not args.no_extra and args.workload == "config2"
+            and args.geom == "llama"):
+        pool.close()
+        pool = None
+        del q, tabs, ctx, out
+        torch.cuda.empty_cache()
+        multi = {}
+        dog = Watchdog(args.extra_timeout, rank, line if rank == 0 else None, multi)
+        try:
+            multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red_dev, barrier, multi)
+        except Exception as exc:  # noqa: BLE001 -- the headline must still be printed
+            multi["error"] = f"{type(exc).__name__}: {exc}"[:300]
+        if not dog.finish():
+            return  # the watchdog is printing (or has printed) the line and ends the process
+        if rank == 0:
+            line["multi_gpu_workloads"] = multi
+    if rank == 0:
         print(json.dumps(line), flush=True)
 
     if pool is not None:
         pool.close()
     if world > 1:
+        sys.stdout.flush()
+        if multi is not None and "error" in multi:
+            os._exit(0)  # ranks may have left the extras at different points: no further collective is safe
+        dog = Watchdog(20.0, rank, None, {})  # (a peer that left that way never answers the shutdown handshake)
         dist.destroy_process_group()
+        dog.finish()
 
 
 if __name__ == "__main__":
