@@ -692,8 +692,95 @@ template <int VPL, int QPK, bool FULL, int KPW> __device__ __forceinline__ void 
         }
     }
 
-    // token-split: the workgroup's sub-ranges of one kv-head meet in LDS; part 0 carries on with the sum
+    // token-split: the workgroup's sub-ranges of one kv-head meet in LDS.  Every part leaves its (m, l, o); after the
+    // barrier the merge is dealt over ALL threads of the workgroup, one output float4 each, every part's record
+    // loaded at once -- one LDS latency where one wave walking the parts paid one per part and q-head (4/1/128 at
+    // config-2 size: 5.5 us of a 28 us kernel, profiles/r02_config2_wg_timeline.log) -- and each thread stores its
+    // float4 straight to `out` (one chunk) or to the chunk's partial.  Same sums in the same order as before: part 0
+    // first, then the parts by index.
     if (parts > 1) {
+#ifndef NVK_SERIAL_PART_MERGE
+        constexpr int kRec  = 4 + VPL * 64; // floats per (wave, q-head): m, l, pad, pad, then o as [VPL][16] float4
+        constexpr int kVecs = VPL * 16;     // float4 per (kv-head, q-head)
+        constexpr int kMaxParts = 8;
+        float        *s_mrg = reinterpret_cast<float *>(s_tab + p.merge_off);
+        if (slot == 0) {
+#pragma unroll
+            for (int h = 0; h < QPK; h++) {
+                float *rec = s_mrg + ((wave * KPW + hsub) * QPK + h) * kRec;
+                if (r == 0)
+                    rec[0] = m[h], rec[1] = l[h];
+#pragma unroll
+                for (int j = 0; j < VPL; j++)
+                    *reinterpret_cast<float4 *>(rec + 4 + (j * 16 + r) * 4) = o[h][j];
+            }
+        }
+        __syncthreads();
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        constexpr int kSc1  = 16; // aux bit 4 of the buffer instructions on gfx950: write-through, see below
+        const int     total = p.kv_waves * KPW * QPK * kVecs;
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+            const int vec = idx % kVecs, hh = idx / kVecs; // hh = (kv slot, head of the pair, q-head)
+            const int h = hh % QPK, ks = hh / QPK;         // ks = kw * KPW + hsub
+            const int kvh_i = kvg * p.kv_waves * KPW + ks;
+            if (kvh_i >= p.n_kv_heads || 4 * vec >= hd)
+                continue;
+            const int    kw = ks / KPW, hs = ks - kw * KPW;
+            float        pm[kMaxParts], pl[kMaxParts];
+            float4       po[kMaxParts];
+#pragma unroll
+            for (int q = 0; q < kMaxParts; q++) {
+                pm[q] = kNegBig, pl[q] = 0.f, po[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < parts) {
+                    const float *rec = s_mrg + ((((q * p.kv_waves + kw) * KPW + hs) * QPK + h)) * kRec;
+                    pm[q] = rec[0], pl[q] = rec[1];
+                    po[q] = *reinterpret_cast<const float4 *>(rec + 4 + vec * 4);
+                }
+            }
+            float mw = pm[0];
+#pragma unroll
+            for (int q = 1; q < kMaxParts; q++)
+                if (q < parts)
+                    mw = fmaxf(mw, pm[q]);
+            const float f0 = fast_exp2(pm[0] - mw);
+            float       lw = pl[0] * f0;
+            float4      a  = make_float4(po[0].x * f0, po[0].y * f0, po[0].z * f0, po[0].w * f0);
+#pragma unroll
+            for (int q = 1; q < kMaxParts; q++)
+                if (q < parts) {
+                    const float f = fast_exp2(pm[q] - mw);
+                    lw            = fmaf(pl[q], f, lw);
+                    a.x = fmaf(po[q].x, f, a.x), a.y = fmaf(po[q].y, f, a.y);
+                    a.z = fmaf(po[q].z, f, a.z), a.w = fmaf(po[q].w, f, a.w);
+                }
+            const int head = kvh_i * p.kv_mul + zq * QPK + h;
+            if (nch == 1) {
+                const float mf  = fmaxf(mw, kRefMaxFloorLog2); // the reference's -1e10 floor, as below
+                const float f   = fast_exp2(mw - mf);
+                const float inv = f / (lw * f);
+                *reinterpret_cast<float4 *>(p.out + ((int64_t)seq * p.n_heads + head) * hd + 4 * vec) =
+                    make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+            }
+            else {
+                const int64_t slab = (int64_t)seq * p.max_chunks + chunk;
+                const __amdgpu_buffer_rsrc_t rs_o =
+                    __builtin_amdgcn_make_buffer_rsrc(p.ws_o + slab * p.n_heads * hd, 0, p.n_heads * hd * 4, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rs_o, (head * hd + 4 * vec) * 4, 0,
+                                                       kSc1);
+                if (vec == 0) {
+                    const __amdgpu_buffer_rsrc_t rs_ml =
+                        __builtin_amdgcn_make_buffer_rsrc(p.ws_ml + slab * p.n_heads * 2, 0, p.n_heads * 8, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(mw, lw)), rs_ml, head * 8,
+                                                          0, kSc1);
+                }
+            }
+        }
+        if (!fused)
+            return;
+        combine_if_last(p, s_tab, seq, nch, kvg, zq, qsplit, QPK, KPW);
+        return;
+#else
         constexpr int kRec = 4 + VPL * 64; // floats per (wave, q-head): m, l, pad, pad, then o as [VPL][16] float4
         float        *s_mrg = reinterpret_cast<float *>(s_tab + p.merge_off);
         if (slot == 0 && part > 0) {
@@ -739,6 +826,7 @@ template <int VPL, int QPK, bool FULL, int KPW> __device__ __forceinline__ void 
                     o[h][j] = a[j];
             }
         }
+#endif
     }
 
     const bool writer = live && slot == 0 && part == 0; // the lanes that hold the chunk's (m, l, o)

@@ -55,6 +55,10 @@ dist("main loop end", us(s[ok, 2]))
 ok = s[:, 4] > 0
 if ok.any():
     dist("store+drain+barrier (4 - 2)", (s[ok, 4] - s[ok, 2]) / 100.0)
+    ok3 = ok & (s[:, 3] > 0)
+    if ok3.any():
+        dist("  wave join + partial stored (3 - 2)", (s[ok3, 3] - s[ok3, 2]) / 100.0)
+        dist("  drain + barrier (4 - 3)", (s[ok3, 4] - s[ok3, 3]) / 100.0)
     dist("arrival known (5 - 4)", (s[ok, 5] - s[ok, 4]) / 100.0)
     red = s[:, 6] > 0
     dist("combine (6 - 5), reducers", (s[red, 6] - s[red, 5]) / 100.0)
