@@ -316,8 +316,25 @@ __device__ __forceinline__ void merge_chunks(const float *ws_o, const float *ws_
     const float  *po = ws_o + (row * max_chunks * n_heads + head) * head_dim + 4 * vec;
     const int64_t ml_step = (int64_t)n_heads * 2, o_step = (int64_t)n_heads * head_dim;
 
+    // the first four chunks' partials are requested before anything waits on them (most launches have no more than
+    // four chunks per sequence: one load latency for the whole combine instead of one for the maxima and one for
+    // the sums); same arithmetic in the same order as a plain two-pass walk
+    float2 s0[4];
+    float4 a0[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        s0[u] = make_float2(kRefMaxFloorLog2, 0.f);
+        a0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < nch) {
+            s0[u] = *reinterpret_cast<const float2 *>(ml + u * ml_step);
+            a0[u] = *reinterpret_cast<const float4 *>(po + u * o_step);
+        }
+    }
     float top = kRefMaxFloorLog2; // the reference's -1e10 floor, see nvk_decode_kernel
-    for (int c = 0; c < nch; c++)
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        top = fmaxf(top, s0[u].x); // (slots past nch hold the floor itself)
+    for (int c = 4; c < nch; c++)
         top = fmaxf(top, ml[c * ml_step]);
     float  denom = 0.f;
     float4 acc   = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -329,7 +346,11 @@ __device__ __forceinline__ void merge_chunks(const float *ws_o, const float *ws_
         acc.z         = fmaf(a.z, f, acc.z);
         acc.w         = fmaf(a.w, f, acc.w);
     };
-    int c = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+        if (u < nch)
+            add(s0[u], a0[u]);
+    int c = 4;
     for (; c + 4 <= nch; c += 4) {
         float2 s[4];
         float4 a[4];
