@@ -48,6 +48,9 @@
 #ifndef NVK_NT_LOADS
 #define NVK_NT_LOADS 1 // 1: K/V loads carry the non-temporal hint (read-once stream)
 #endif
+#ifndef NVK_LOCKSTEP
+#define NVK_LOCKSTEP 1 // 1: the waves of a workgroup are kept on the same token rows (see decode_body); 0 for A/B
+#endif
 
 #include "nvk_addr.hip.h" // token_block, token_offset, row_float_index, clamp_block, rope_rotate
 
@@ -426,7 +429,9 @@ __device__ __forceinline__ void combine_if_last(const DecodeParams &p, int *s_fl
 // chunk's tokens ("token-split"):
 // wave w takes sub-range w / kv_waves, and the sub-ranges are merged through LDS at the end, so a
 // workgroup keeps 8 waves of loads in flight whatever the head count.
-template <int VPL, int QPK, bool FULL, int KPW> __device__ __forceinline__ void decode_body(const DecodeParams &p)
+// LOCK  the workgroup holds EVERY kv-head of its token rows (one kv-head group): its waves are kept in step, see below
+template <int VPL, int QPK, bool FULL, int KPW, bool LOCK>
+__device__ __forceinline__ void decode_body(const DecodeParams &p)
 {
     static_assert(KPW == 1 || (KPW == 2 && VPL == 1 && !FULL), "kv-head pairs are for short odd rows only");
     constexpr int  kTokPerLane = tok_per_lane(VPL, QPK);       // tokens each lane holds per step
@@ -663,11 +668,29 @@ template <int VPL, int QPK, bool FULL, int KPW> __device__ __forceinline__ void 
     // or two steps (the only ones that can run past the chunk's end) are peeled off.
     const std::integral_constant<bool, false> body;
     const std::integral_constant<bool, true>  tail;
+    // Lockstep: the waves of a workgroup are the kv-heads (and token parts) of the SAME token rows, and the stream
+    // runs fastest when they ask for those rows together -- left alone, the older wave of each SIMD runs up to 10 %
+    // of the chunk ahead of the younger one (profiles/r02_wave_timeline.log) and the workgroup's requests spread
+    // over more DRAM pages.  A bare s_barrier (no wait on the loads in flight) at the top of every double-step keeps
+    // them within one: config 2 0.82 -> 0.85 of the HBM peak, 5b 0.87 -> 0.89 (profiles/r02_variants_lockstep.log).
+    // Only where the workgroup holds every kv-head of the row (several kv-head groups, e.g. MHA's 32 heads, are
+    // different workgroups that no barrier joins: measured 2 % slower there; those launch nvk_decode_free_kernel,
+    // this code without the barrier) and every wave is live; the barriers are counted from the steps EVERY wave
+    // runs (token parts differ by at most one step).  Not for 256-float rows (one wave per SIMD: nothing drifts;
+    // measured 3 % slower), nor for 8 q-heads over whole 64-float rows (the MFMA kernel's shape unless
+    // NVK_DECODE_VECTOR_ONLY forces this one: the branch costs the instantiation its last registers).
+    constexpr bool kLock = LOCK && NVK_LOCKSTEP && KPW == 1 && VPL < 4 && !(VPL == 1 && QPK == 8 && FULL);
+    const int locked_upto = kLock && p.n_kv_heads == p.kv_waves
+                                ? (t1 - t0 + kStepTokens - 1) / kStepTokens / parts // steps of the part with the fewest
+                                : 0;
     if (has_tokens) {
         Tile        ta, tb;
         int         k = 0;
         load_tile(ta, w0);
         for (; k + 2 < nsteps; k += 2) {
+            if constexpr (kLock)
+                if (k + 2 < locked_upto)
+                    __builtin_amdgcn_s_barrier();
             load_tile(tb, w0 + (k + 1) * stride);
             consume_tile(ta, w0 + k * stride, body);
             load_tile(ta, w0 + (k + 2) * stride);
@@ -904,7 +927,16 @@ template <int VPL, int QPK, bool FULL>
 __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_PER_EU)
     nvk_decode_kernel(const DecodeParams p)
 {
-    decode_body<VPL, QPK, FULL, 1>(p);
+    decode_body<VPL, QPK, FULL, 1, true>(p);
+}
+
+// the same for pools with more kv-heads than a workgroup has waves (several kv-head groups per token row, e.g. MHA):
+// the waves run free
+template <int VPL, int QPK, bool FULL>
+__global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_PER_EU)
+    nvk_decode_free_kernel(const DecodeParams p)
+{
+    decode_body<VPL, QPK, FULL, 1, false>(p);
 }
 
 // rows of 64 / 192 B (head_dim 16 / 48), an even number of kv-heads: a pair of adjacent kv-heads per wave (KPW = 2)
@@ -912,7 +944,7 @@ template <int QPK>
 __global__ void __launch_bounds__(64 * wg_waves(1, QPK, false), NVK_MIN_WAVES_PER_EU)
     nvk_decode_pairs_kernel(const DecodeParams p)
 {
-    decode_body<1, QPK, false, 2>(p);
+    decode_body<1, QPK, false, 2, false>(p);
 }
 
 // ---- the decode kernel on fp32 MFMA tiles, for GQA groups of 5..16 q-heads --------------------------------

@@ -392,9 +392,26 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     return NVK_OK;
 }
 
+// Which of the two vector kernels a shape launches: nvk_decode_kernel keeps the workgroup's waves in step and is for
+// workgroups that hold every kv-head of their token rows; several kv-head groups (and 256-float rows, whose code is
+// the same in both) run nvk_decode_free_kernel / nvk_decode_kernel without it.
+// (6 q-heads over 128-float rows stay with nvk_decode_kernel, whose barrier is then off at run time: the free-running
+// instantiation of that one shape comes out of the register allocator with 4 registers in scratch.)
+constexpr bool has_free_kernel(int vpl, int qpk) { return vpl < 4 && !(vpl == 2 && qpk == 6); }
+bool free_running(const LaunchShape &plan) { return plan.kv_groups > 1 && has_free_kernel(plan.vpl, plan.qpk); }
+
 template <int VPL, int QPK> hipError_t launch_decode_full(bool full, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
                                                          const nvk::DecodeParams &p)
 {
+    if constexpr (has_free_kernel(VPL, QPK)) {
+        if (p.n_kv_heads != p.kv_waves) { // several kv-head groups: see free_running
+            if (full)
+                hipLaunchKernelGGL((nvk::nvk_decode_free_kernel<VPL, QPK, true>), grid, block, lds, stream, p);
+            else
+                hipLaunchKernelGGL((nvk::nvk_decode_free_kernel<VPL, QPK, false>), grid, block, lds, stream, p);
+            return hipGetLastError();
+        }
+    }
     if (full)
         hipLaunchKernelGGL((nvk::nvk_decode_kernel<VPL, QPK, true>), grid, block, lds, stream, p);
     else
@@ -1894,7 +1911,8 @@ int nvk_decode_kernel_name(nvk_pool *pool, int num_seqs, int n_heads, int max_ct
     else if (sh.kpw == 2)
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_pairs_kernel<%d>", sh.qpk);
     else
-        snprintf(buf, (size_t)cap, "nvk::nvk_decode_kernel<%d, %d, %s>", sh.vpl, sh.qpk, sh.full ? "true" : "false");
+        snprintf(buf, (size_t)cap, "nvk::nvk_decode_%skernel<%d, %d, %s>", free_running(sh) ? "free_" : "", sh.vpl, sh.qpk,
+                 sh.full ? "true" : "false");
     return NVK_OK;
 }
 
