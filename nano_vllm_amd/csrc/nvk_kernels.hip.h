@@ -430,13 +430,16 @@ __device__ __forceinline__ void combine_if_last(const DecodeParams &p, int *s_fl
 // wave w takes sub-range w / kv_waves, and the sub-ranges are merged through LDS at the end, so a
 // workgroup keeps 8 waves of loads in flight whatever the head count.
 // LOCK  the workgroup holds EVERY kv-head of its token rows (one kv-head group): its waves are kept in step, see below
-template <int VPL, int QPK, bool FULL, int KPW, bool LOCK>
+// WIDE  16-token steps instead of 8 (whole 128-float rows, up to 4 q-heads): a step of the workgroup is then one whole
+//       64-KiB block of K and one of V at block_size 16.  For long chunks: config 3 0.84 -> 0.86, config 4 +2 %.
+template <int VPL, int QPK, bool FULL, int KPW, bool LOCK, bool WIDE = false>
 __device__ __forceinline__ void decode_body(const DecodeParams &p)
 {
+    static_assert(!WIDE || (VPL == 2 && QPK <= 4 && FULL && KPW == 1), "16-token steps: registers were counted for these");
     static_assert(KPW == 1 || (KPW == 2 && VPL == 1 && !FULL), "kv-head pairs are for short odd rows only");
-    constexpr int  kTokPerLane = tok_per_lane(VPL, QPK);       // tokens each lane holds per step
+    constexpr int  kTokPerLane = WIDE ? 4 : tok_per_lane(VPL, QPK); // tokens each lane holds per step
     constexpr int  kSlots      = 4 / KPW;                      // token slots of a wave (16-lane rows per kv-head)
-    constexpr int  kStepTokens = step_tokens(VPL, QPK) / KPW;  // tokens per wave per pipeline step
+    constexpr int  kStepTokens = 4 * kTokPerLane / KPW;        // tokens per wave per pipeline step
     constexpr bool kStream     = FULL || KPW == 2;             // row pieces are whole lines: read-once hint
     using Tile                = KVTile<VPL, kTokPerLane>;
     extern __shared__ __attribute__((aligned(16))) int s_tab[]; // this chunk's block-table slice (+ merge area)
@@ -928,6 +931,13 @@ __global__ void __launch_bounds__(64 * wg_waves(VPL, QPK, FULL), NVK_MIN_WAVES_P
     nvk_decode_kernel(const DecodeParams p)
 {
     decode_body<VPL, QPK, FULL, 1, true>(p);
+}
+
+// whole 128-float rows in 16-token steps (WIDE), for chunks of 1024 tokens and more that no token parts split
+template <int QPK>
+__global__ void __launch_bounds__(64 * wg_waves(2, QPK, true), NVK_MIN_WAVES_PER_EU) nvk_decode_wide_kernel(const DecodeParams p)
+{
+    decode_body<2, QPK, true, 1, true, true>(p);
 }
 
 // the same for pools with more kv-heads than a workgroup has waves (several kv-head groups per token row, e.g. MHA):

@@ -40,6 +40,12 @@
 #ifndef NVK_AUTO_MAX_CHUNK
 #define NVK_AUTO_MAX_CHUNK 2048 // longest chunk NVK_DECODE_AUTO picks
 #endif
+#ifndef NVK_WIDE_STEPS
+#define NVK_WIDE_STEPS 1 // 1: chunks of NVK_WIDE_MIN_CHUNK tokens and more run nvk_decode_wide_kernel (16-token steps); 0 for A/B
+#endif
+#ifndef NVK_WIDE_MIN_CHUNK
+#define NVK_WIDE_MIN_CHUNK 1024
+#endif
 #ifndef NVK_MFMA_MIN_KVMUL
 #define NVK_MFMA_MIN_KVMUL 5 // q-heads per kv-head from which decode runs on fp32 MFMA tiles (head_dim 64 or 128, <= 16 heads)
 #endif
@@ -279,6 +285,7 @@ struct LaunchShape
     bool full        = false;
     bool mfma        = false; // nvk_decode_mfma_kernel: one wave carries the whole GQA group on 16-token MFMA tiles
     int  kpw         = 1;     // kv-heads per wave: 2 where a row is an odd number of half-lines (head_dim 16 / 48)
+    bool wide        = false; // nvk_decode_wide_kernel: 16-token steps (long chunks of whole 128-float rows, no token parts)
     size_t lds_bytes = 0;
     int  qgroups     = 1;     // (kv-head group, q sub-group) pairs per item = arrival counters per row
     bool fuse_merge  = false; // max_chunks > 1: the decode kernel combines a row's chunks itself
@@ -381,6 +388,11 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
                          plan->chunk_tokens, max_ctx);
     if ((unsigned long long)max_ctx * (unsigned)pool->block_size >= (1ULL << 32))
         return nvk::fail(NVK_ERR_INVALID_ARG, "max_ctx=%d too long for block_size=%d", max_ctx, pool->block_size);
+    // long chunks of whole 128-float rows that the workgroup's waves walk together: 16-token steps (measured: config 3
+    // 0.84 -> 0.86 of the HBM peak, config 4 +2 %; 512-token chunks and token-split shapes do better with 8)
+    plan->wide = NVK_WIDE_STEPS && !plan->mfma && plan->kpw == 1 && plan->vpl == 2 && plan->full && plan->qpk <= 4
+                 && plan->kv_groups == 1 && plan->parts == 1 && plan->chunk_tokens >= NVK_WIDE_MIN_CHUNK
+                 && plan->chunk_tokens % 16 == 0;
     plan->merge_off    = (plan->chunk_tokens / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
     plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int);
     if (plan->parts > 1)
@@ -454,6 +466,15 @@ hipError_t launch_decode(const LaunchShape &plan, dim3 grid, dim3 block, hipStre
             hipLaunchKernelGGL((nvk::nvk_decode_mfma_kernel<64>), grid, block, plan.lds_bytes, stream, p);
         else
             hipLaunchKernelGGL((nvk::nvk_decode_mfma_kernel<128>), grid, block, plan.lds_bytes, stream, p);
+        return hipGetLastError();
+    }
+    if (plan.wide) { // make_shape: vpl 2, full, at most 4 q-heads per wave, one kv-head group, no token parts
+        switch (plan.qpk) {
+        case 4: hipLaunchKernelGGL((nvk::nvk_decode_wide_kernel<4>), grid, block, plan.lds_bytes, stream, p); break;
+        case 3: hipLaunchKernelGGL((nvk::nvk_decode_wide_kernel<3>), grid, block, plan.lds_bytes, stream, p); break;
+        case 2: hipLaunchKernelGGL((nvk::nvk_decode_wide_kernel<2>), grid, block, plan.lds_bytes, stream, p); break;
+        default: hipLaunchKernelGGL((nvk::nvk_decode_wide_kernel<1>), grid, block, plan.lds_bytes, stream, p); break;
+        }
         return hipGetLastError();
     }
     switch (plan.vpl) {
@@ -1910,6 +1931,8 @@ int nvk_decode_kernel_name(nvk_pool *pool, int num_seqs, int n_heads, int max_ct
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_mfma_kernel<%d>", 64 * sh.vpl);
     else if (sh.kpw == 2)
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_pairs_kernel<%d>", sh.qpk);
+    else if (sh.wide)
+        snprintf(buf, (size_t)cap, "nvk::nvk_decode_wide_kernel<%d>", sh.qpk);
     else
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_%skernel<%d, %d, %s>", free_running(sh) ? "free_" : "", sh.vpl, sh.qpk,
                  sh.full ? "true" : "false");
