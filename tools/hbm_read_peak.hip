@@ -38,6 +38,31 @@ template <int UNROLL> __global__ void __launch_bounds__(512) read_kernel(const v
         out[0] = acc.x;
 }
 
+// The decode kernel's shape of access instead of a grid-stride walk: workgroup w streams ONE contiguous region, 4-KiB rows,
+// wave v the v-th 512-B piece of 8 consecutive rows per step (16 lanes x 16 B x 2 per row piece, 4 rows per instruction
+// pair), two steps in flight.  LOCK: a bare s_barrier per step keeps the workgroup's 8 waves on the same rows.
+template <bool LOCK> __global__ void __launch_bounds__(512) rows_kernel(const v4f *__restrict__ src, size_t rows_per_wg, float *out)
+{
+    const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t row0 = (size_t)blockIdx.x * rows_per_wg;
+    // float4 index of (row, wave piece, lane): a row is 256 float4, a piece 32 float4; lane -> (row of 4, 16 lanes)
+    const v4f *base = src + row0 * 256 + wave * 32 + (lane >> 4) * 256 + (lane & 15);
+    v4f        acc  = {0.f, 0.f, 0.f, 0.f};
+    for (size_t r = 0; r + 8 <= rows_per_wg; r += 8) {
+        if (LOCK)
+            __builtin_amdgcn_s_barrier();
+        const v4f *p = base + r * 256;
+        v4f        t[4];
+        t[0] = __builtin_nontemporal_load(p);
+        t[1] = __builtin_nontemporal_load(p + 16);
+        t[2] = __builtin_nontemporal_load(p + 4 * 256);
+        t[3] = __builtin_nontemporal_load(p + 4 * 256 + 16);
+        acc += t[0] + t[1] + t[2] + t[3];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f)
+        out[0] = acc.x;
+}
+
 int main(int argc, char **argv)
 {
     const double gib = argc > 1 ? atof(argv[1]) : 4.0;
@@ -68,6 +93,30 @@ int main(int argc, char **argv)
                 best = ms;
         }
         printf("  %d workgroups of 512 per CU: %8.3f ms  %7.1f GB/s\n", wgs_per_cu, best, n4 * 16 / (best * 1e-3) / 1e9);
+    }
+    // one contiguous region per workgroup, whole 4-KiB rows by its 8 waves (the decode kernel's pattern), free-running and
+    // in lockstep; 2 workgroups per CU's worth of regions, one workgroup resident per CU at a time is not enforced here
+    for (int wgs_per_cu : {1, 2}) {
+        const int    grid = prop.multiProcessorCount * wgs_per_cu;
+        const size_t rows = (n4 / 256 / grid) / 8 * 8;
+        for (int lock = 0; lock < 2; lock++) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 6; rep++) {
+                CHECK(hipEventRecord(a));
+                if (lock)
+                    hipLaunchKernelGGL(rows_kernel<true>, dim3(grid), dim3(512), 0, 0, buf, rows, out);
+                else
+                    hipLaunchKernelGGL(rows_kernel<false>, dim3(grid), dim3(512), 0, 0, buf, rows, out);
+                CHECK(hipEventRecord(b));
+                CHECK(hipEventSynchronize(b));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, a, b));
+                if (rep > 0 && ms < best)
+                    best = ms;
+            }
+            printf("  rows: %d workgroups per CU, one contiguous region each, %s: %8.3f ms  %7.1f GB/s\n", wgs_per_cu,
+                   lock ? "waves in lockstep" : "waves free-running", best, (double)rows * grid * 4096 / (best * 1e-3) / 1e9);
+        }
     }
     // a launch the size of config 2 (1.08 GB): the ramp-up and the tail are part of a 160 us kernel
     const size_t small4 = (size_t)1075871744 / 16;
