@@ -134,5 +134,23 @@ int main(int argc, char **argv)
     }
     printf("  1.076 GB (config 2's bytes), rotating over 3 regions: %8.1f us  %7.1f GB/s\n", best * 1e3,
            small4 * 16 / (best * 1e-3) / 1e9);
+    // the same bytes in the decode kernel's shape: 256 workgroups, one contiguous 4.2-MB region each
+    {
+        const int    grid = prop.multiProcessorCount;
+        const size_t rows = (small4 / 256 / grid) / 8 * 8;
+        best              = 1e30f;
+        for (int rep = 0; rep < 10; rep++) {
+            CHECK(hipEventRecord(a));
+            hipLaunchKernelGGL(rows_kernel<false>, dim3(grid), dim3(512), 0, 0, buf + (rep % 3) * small4, rows, out);
+            CHECK(hipEventRecord(b));
+            CHECK(hipEventSynchronize(b));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, a, b));
+            if (rep > 0 && ms < best)
+                best = ms;
+        }
+        printf("  1.076 GB as rows, one region per workgroup, rotating over 3 regions: %8.1f us  %7.1f GB/s\n", best * 1e3,
+               (double)rows * grid * 4096 / (best * 1e-3) / 1e9);
+    }
     return 0;
 }
