@@ -746,7 +746,6 @@ __device__ __forceinline__ void decode_body(const DecodeParams &p)
     // float4 straight to `out` (one chunk) or to the chunk's partial.  Same sums in the same order as before: part 0
     // first, then the parts by index.
     if (parts > 1) {
-#ifndef NVK_SERIAL_PART_MERGE
         constexpr int kRec  = 4 + VPL * 64; // floats per (wave, q-head): m, l, pad, pad, then o as [VPL][16] float4
         constexpr int kVecs = VPL * 16;     // float4 per (kv-head, q-head)
         constexpr int kMaxParts = 8;
@@ -827,53 +826,6 @@ __device__ __forceinline__ void decode_body(const DecodeParams &p)
             return;
         combine_if_last(p, s_tab, seq, nch, kvg, zq, qsplit, QPK, KPW);
         return;
-#else
-        constexpr int kRec = 4 + VPL * 64; // floats per (wave, q-head): m, l, pad, pad, then o as [VPL][16] float4
-        float        *s_mrg = reinterpret_cast<float *>(s_tab + p.merge_off);
-        if (slot == 0 && part > 0) {
-#pragma unroll
-            for (int h = 0; h < QPK; h++) {
-                float *rec = s_mrg + ((wave * KPW + hsub) * QPK + h) * kRec;
-                if (r == 0)
-                    rec[0] = m[h], rec[1] = l[h];
-#pragma unroll
-                for (int j = 0; j < VPL; j++)
-                    *reinterpret_cast<float4 *>(rec + 4 + (j * 16 + r) * 4) = o[h][j];
-            }
-        }
-        __syncthreads();
-        if (part > 0 && !fused)
-            return;
-        if (slot == 0 && part == 0) {
-#pragma unroll
-            for (int h = 0; h < QPK; h++) {
-                float mw = m[h];
-                for (int q = 1; q < parts; q++)
-                    mw = fmaxf(mw, s_mrg[(((q * p.kv_waves + wave) * KPW + hsub) * QPK + h) * kRec]);
-                const float f0 = fast_exp2(m[h] - mw);
-                float       lw = l[h] * f0;
-                float4      a[VPL];
-#pragma unroll
-                for (int j = 0; j < VPL; j++)
-                    a[j] = make_float4(o[h][j].x * f0, o[h][j].y * f0, o[h][j].z * f0, o[h][j].w * f0);
-                for (int q = 1; q < parts; q++) {
-                    const float *rec = s_mrg + (((q * p.kv_waves + wave) * KPW + hsub) * QPK + h) * kRec;
-                    const float  f   = fast_exp2(rec[0] - mw);
-                    lw               = fmaf(rec[1], f, lw);
-#pragma unroll
-                    for (int j = 0; j < VPL; j++) {
-                        const float4 b = *reinterpret_cast<const float4 *>(rec + 4 + (j * 16 + r) * 4);
-                        a[j].x = fmaf(b.x, f, a[j].x), a[j].y = fmaf(b.y, f, a[j].y);
-                        a[j].z = fmaf(b.z, f, a[j].z), a[j].w = fmaf(b.w, f, a[j].w);
-                    }
-                }
-                m[h] = mw, l[h] = lw;
-#pragma unroll
-                for (int j = 0; j < VPL; j++)
-                    o[h][j] = a[j];
-            }
-        }
-#endif
     }
 
     const bool writer = live && slot == 0 && part == 0; // the lanes that hold the chunk's (m, l, o)
