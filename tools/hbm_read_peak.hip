@@ -63,6 +63,29 @@ template <bool LOCK> __global__ void __launch_bounds__(512) rows_kernel(const v4
         out[0] = acc.x;
 }
 
+// MHA's shape: a token row is PIECES x 4 KiB and a workgroup (WAVES waves, 512 B each) reads one piece of WAVES / 8 x 4 KiB of
+// every row of its region; the row's other pieces belong to workgroups that run at another time (kv-head group outermost).
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) strided_kernel(const v4f *__restrict__ src, size_t rows_per_wg, int row_f4, int wgs_per_region,
+                                                             float *out)
+{
+    const int    lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t region = blockIdx.x % wgs_per_region, piece = blockIdx.x / wgs_per_region; // piece outermost, as kv-head groups are
+    const v4f   *base = src + region * rows_per_wg * row_f4 + piece * (WAVES * 32) + wave * 32 + (size_t)(lane >> 4) * row_f4 + (lane & 15);
+    v4f          acc  = {0.f, 0.f, 0.f, 0.f};
+    for (size_t r = 0; r + 8 <= rows_per_wg; r += 8) {
+        const v4f *p = base + r * row_f4;
+        v4f        t[4];
+        t[0] = __builtin_nontemporal_load(p);
+        t[1] = __builtin_nontemporal_load(p + 16);
+        t[2] = __builtin_nontemporal_load(p + 4 * (size_t)row_f4);
+        t[3] = __builtin_nontemporal_load(p + 4 * (size_t)row_f4 + 16);
+        acc += t[0] + t[1] + t[2] + t[3];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f)
+        out[0] = acc.x;
+}
+
 int main(int argc, char **argv)
 {
     const double gib = argc > 1 ? atof(argv[1]) : 4.0;
@@ -116,6 +139,32 @@ int main(int argc, char **argv)
             }
             printf("  rows: %d workgroups per CU, one contiguous region each, %s: %8.3f ms  %7.1f GB/s\n", wgs_per_cu,
                    lock ? "waves in lockstep" : "waves free-running", best, (double)rows * grid * 4096 / (best * 1e-3) / 1e9);
+        }
+    }
+    // MHA 32/32/128: 16-KiB token rows; 8-wave workgroups read 4-KiB pieces (4 per row), 16-wave workgroups 8-KiB pieces (2 per row)
+    {
+        const int    row_f4 = 1024;                       // 16 KiB
+        const size_t rows_all = n4 / row_f4;
+        const int    regions = 512;                       // "items": contiguous runs of rows
+        const size_t rows = rows_all / regions / 8 * 8;
+        for (int waves : {8, 16}) {
+            const int pieces = 32 / waves;
+            float     best = 1e30f;
+            for (int rep = 0; rep < 6; rep++) {
+                CHECK(hipEventRecord(a));
+                if (waves == 8)
+                    hipLaunchKernelGGL(strided_kernel<8>, dim3(regions * pieces), dim3(512), 0, 0, buf, rows, row_f4, regions, out);
+                else
+                    hipLaunchKernelGGL(strided_kernel<16>, dim3(regions * pieces), dim3(1024), 0, 0, buf, rows, row_f4, regions, out);
+                CHECK(hipEventRecord(b));
+                CHECK(hipEventSynchronize(b));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, a, b));
+                if (rep > 0 && ms < best)
+                    best = ms;
+            }
+            printf("  16-KiB rows in %d pieces by %d-wave workgroups (piece outermost): %8.3f ms  %7.1f GB/s\n", pieces, waves, best,
+                   (double)rows * regions * row_f4 * 16 / (best * 1e-3) / 1e9);
         }
     }
     // a launch the size of config 2 (1.08 GB): the ramp-up and the tail are part of a 160 us kernel
