@@ -465,6 +465,9 @@ def main():
                          "clocks have reached their steady state when the timed region starts (0 = off)")
     ap.add_argument("--no-pairs", action="store_true",
                     help="diagnostic: rows of 64 / 192 B one kv-head per wave (NVK_DECODE_NO_PAIRS)")
+    ap.add_argument("--free-running", action="store_true",
+                    help="diagnostic: the vector kernel without the lockstep barrier and with 8-token steps "
+                         "(NVK_DECODE_FREE_RUNNING)")
     ap.add_argument("--no-extra", action="store_true",
                     help="N=1 only: skip the extra BASELINE configs (3, 4, 5a, 5b) timed after the headline workload")
     ap.add_argument("--extra-timeout", type=float, default=150.0,
@@ -513,6 +516,8 @@ def main():
     flags |= {"auto": 0, "kernel": nv.MERGE_IN_KERNEL, "separate": nv.MERGE_SEPARATE}[args.merge]
     if args.no_pairs:
         flags |= nv.NO_PAIRS
+    if args.free_running:
+        flags |= nv.FREE_RUNNING
     uniform_batch = bool((work.ctx_lens == work.ctx_lens[0]).all())
     if args.plan == "none" or (args.plan == "auto" and uniform_batch):
         flags |= nv.UNIFORM if uniform_batch else nv.NO_PLAN

@@ -61,6 +61,12 @@ extern "C" {
  * in another order: same tolerance, not the same bits).  This modifier keeps such a launch on one head per wave
  * (A/B, tests). */
 #define NVK_DECODE_NO_PAIRS 0x2000
+/* The vector kernel keeps the waves of a workgroup -- the kv-heads (or token parts) of the same token rows -- in step
+ * with a barrier per double-step, and walks chunks of 1024 tokens and more in 16-token steps; both are about WHEN rows
+ * are asked for, not about what is computed.  This modifier launches the free-running kernel with 8-token steps instead
+ * (the code path of pools with more kv-heads than a workgroup has waves), where it exists: same bits for 8-token-step
+ * shapes, same tolerance otherwise (A/B, tests). */
+#define NVK_DECODE_FREE_RUNNING 0x4000
 
 /* prefill flags */
 #define NVK_PREFILL_AUTO 0    /* library picks by chunk length                                      */

@@ -28,6 +28,7 @@ UNIFORM = _capi.DECODE_UNIFORM
 NO_PLAN = _capi.DECODE_NO_PLAN
 VECTOR_ONLY = _capi.DECODE_VECTOR_ONLY
 NO_PAIRS = _capi.DECODE_NO_PAIRS
+FREE_RUNNING = _capi.DECODE_FREE_RUNNING
 
 
 def bind_pool(pool: Optional[PagedKVPool], layer: int = 0) -> None:

@@ -286,6 +286,7 @@ struct LaunchShape
     bool mfma        = false; // nvk_decode_mfma_kernel: one wave carries the whole GQA group on 16-token MFMA tiles
     int  kpw         = 1;     // kv-heads per wave: 2 where a row is an odd number of half-lines (head_dim 16 / 48)
     bool wide        = false; // nvk_decode_wide_kernel: 16-token steps (long chunks of whole 128-float rows, no token parts)
+    bool free_forced = false; // NVK_DECODE_FREE_RUNNING: nvk_decode_free_kernel (no lockstep, 8-token steps) wherever it exists
     size_t lds_bytes = 0;
     int  qgroups     = 1;     // (kv-head group, q sub-group) pairs per item = arrival counters per row
     bool fuse_merge  = false; // max_chunks > 1: the decode kernel combines a row's chunks itself
@@ -299,7 +300,7 @@ bool decode_flags_ok(int flags)
     if (mode != NVK_DECODE_AUTO && mode != NVK_DECODE_SINGLE_PASS && mode != NVK_DECODE_SPLIT_K)
         return false;
     if (mods & ~(NVK_DECODE_MERGE_IN_KERNEL | NVK_DECODE_MERGE_SEPARATE | NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN
-                 | NVK_DECODE_VECTOR_ONLY | NVK_DECODE_NO_PAIRS))
+                 | NVK_DECODE_VECTOR_ONLY | NVK_DECODE_NO_PAIRS | NVK_DECODE_FREE_RUNNING))
         return false;
     return !((mods & NVK_DECODE_MERGE_IN_KERNEL) && (mods & NVK_DECODE_MERGE_SEPARATE));
 }
@@ -390,7 +391,8 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
         return nvk::fail(NVK_ERR_INVALID_ARG, "max_ctx=%d too long for block_size=%d", max_ctx, pool->block_size);
     // long chunks of whole 128-float rows that the workgroup's waves walk together: 16-token steps (measured: config 3
     // 0.84 -> 0.86 of the HBM peak, config 4 +2 %; 512-token chunks and token-split shapes do better with 8)
-    plan->wide = NVK_WIDE_STEPS && !plan->mfma && plan->kpw == 1 && plan->vpl == 2 && plan->full && plan->qpk <= 4
+    plan->free_forced = (mods & NVK_DECODE_FREE_RUNNING) != 0;
+    plan->wide = NVK_WIDE_STEPS && !plan->free_forced && !plan->mfma && plan->kpw == 1 && plan->vpl == 2 && plan->full && plan->qpk <= 4
                  && plan->kv_groups == 1 && plan->parts == 1 && plan->chunk_tokens >= NVK_WIDE_MIN_CHUNK
                  && plan->chunk_tokens % 16 == 0;
     plan->merge_off    = (plan->chunk_tokens / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
@@ -410,13 +412,16 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
 // (6 q-heads over 128-float rows stay with nvk_decode_kernel, whose barrier is then off at run time: the free-running
 // instantiation of that one shape comes out of the register allocator with 4 registers in scratch.)
 constexpr bool has_free_kernel(int vpl, int qpk) { return vpl < 4 && !(vpl == 2 && qpk == 6); }
-bool free_running(const LaunchShape &plan) { return plan.kv_groups > 1 && has_free_kernel(plan.vpl, plan.qpk); }
+bool free_running(const LaunchShape &plan)
+{
+    return (plan.kv_groups > 1 || plan.free_forced) && has_free_kernel(plan.vpl, plan.qpk);
+}
 
-template <int VPL, int QPK> hipError_t launch_decode_full(bool full, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
-                                                         const nvk::DecodeParams &p)
+template <int VPL, int QPK> hipError_t launch_decode_full(bool full, bool free_run, dim3 grid, dim3 block, size_t lds,
+                                                         hipStream_t stream, const nvk::DecodeParams &p)
 {
     if constexpr (has_free_kernel(VPL, QPK)) {
-        if (p.n_kv_heads != p.kv_waves) { // several kv-head groups: see free_running
+        if (free_run) { // several kv-head groups, or NVK_DECODE_FREE_RUNNING: see free_running
             if (full)
                 hipLaunchKernelGGL((nvk::nvk_decode_free_kernel<VPL, QPK, true>), grid, block, lds, stream, p);
             else
@@ -431,22 +436,22 @@ template <int VPL, int QPK> hipError_t launch_decode_full(bool full, dim3 grid, 
     return hipGetLastError();
 }
 
-template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
-                                                const nvk::DecodeParams &p)
+template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, bool free_run, dim3 grid, dim3 block, size_t lds,
+                                                hipStream_t stream, const nvk::DecodeParams &p)
 {
     if constexpr (VPL <= 2) {
         if (qpk == 8)
-            return launch_decode_full<VPL, 8>(full, grid, block, lds, stream, p);
+            return launch_decode_full<VPL, 8>(full, free_run, grid, block, lds, stream, p);
         if (qpk == 7)
-            return launch_decode_full<VPL, 7>(full, grid, block, lds, stream, p);
+            return launch_decode_full<VPL, 7>(full, free_run, grid, block, lds, stream, p);
     }
     switch (qpk) {
-    case 6: return launch_decode_full<VPL, 6>(full, grid, block, lds, stream, p);
-    case 5: return launch_decode_full<VPL, 5>(full, grid, block, lds, stream, p);
-    case 4: return launch_decode_full<VPL, 4>(full, grid, block, lds, stream, p);
-    case 3: return launch_decode_full<VPL, 3>(full, grid, block, lds, stream, p);
-    case 2: return launch_decode_full<VPL, 2>(full, grid, block, lds, stream, p);
-    default: return launch_decode_full<VPL, 1>(full, grid, block, lds, stream, p);
+    case 6: return launch_decode_full<VPL, 6>(full, free_run, grid, block, lds, stream, p);
+    case 5: return launch_decode_full<VPL, 5>(full, free_run, grid, block, lds, stream, p);
+    case 4: return launch_decode_full<VPL, 4>(full, free_run, grid, block, lds, stream, p);
+    case 3: return launch_decode_full<VPL, 3>(full, free_run, grid, block, lds, stream, p);
+    case 2: return launch_decode_full<VPL, 2>(full, free_run, grid, block, lds, stream, p);
+    default: return launch_decode_full<VPL, 1>(full, free_run, grid, block, lds, stream, p);
     }
 }
 
@@ -478,9 +483,9 @@ hipError_t launch_decode(const LaunchShape &plan, dim3 grid, dim3 block, hipStre
         return hipGetLastError();
     }
     switch (plan.vpl) {
-    case 1: return launch_decode_qpk<1>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
-    case 2: return launch_decode_qpk<2>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
-    default: return launch_decode_qpk<4>(plan.qpk, plan.full, grid, block, plan.lds_bytes, stream, p);
+    case 1: return launch_decode_qpk<1>(plan.qpk, plan.full, free_running(plan), grid, block, plan.lds_bytes, stream, p);
+    case 2: return launch_decode_qpk<2>(plan.qpk, plan.full, free_running(plan), grid, block, plan.lds_bytes, stream, p);
+    default: return launch_decode_qpk<4>(plan.qpk, plan.full, free_running(plan), grid, block, plan.lds_bytes, stream, p);
     }
 }
 
