@@ -24,7 +24,11 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -78,21 +82,56 @@ def make_workload(name, rank=0, geom="llama"):
 
 
 def profiled_traffic(work_name, kernel):
-    """HBM bytes per launch of `kernel` (the instantiation this run launched, as rocprofv3 names it) from the
-    committed PMC profile of this same workload (profiles/r*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE
-    passes, gfx950 corrections applied as MI355X_MICROARCH.md prescribes).  The latest round wins; None when no
-    profile holds this (workload, kernel) pair -- never a number measured on another kernel."""
+    """(HBM bytes per launch of `kernel`, the committed profile it was read from): the instantiation this run launched,
+    as rocprofv3 names it, looked up in the PMC profile of this same workload (profiles/r*_pmc_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied as MI355X_MICROARCH.md prescribes).  NOT measured in
+    this run -- counters need rocprofv3 around the process -- which is what `traffic_source` in the line says.  The
+    latest round wins; (None, None) when no profile holds this (workload, kernel) pair -- never a number measured on
+    another kernel."""
     import glob
-    best = None
+    best, where = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
         try:
             with open(path) as fh:
                 prof = json.load(fh)
             if prof.get("workload") == work_name and kernel in prof.get("kernels", {}):
-                best = prof["kernels"][kernel].get("hbm_bytes_per_launch_corrected", best)
+                got = prof["kernels"][kernel].get("hbm_bytes_per_launch_corrected")
+                if got is not None:
+                    best, where = got, "profiles/" + os.path.basename(path)
         except (OSError, ValueError):
             continue
-    return best
+    return best, where
+
+
+def self_check(work, out_host, seed_k, seed_v, seqs):
+    """The checker's leg of the line: rows `seqs` of `out` (what the LAST timed launch left in HBM) against the CPU
+    restatement of Attention::paged_attention (oracle/, include/core/attention.hpp:82-159) on the same pool values,
+    at the path's tolerance 1e-4 + 1e-5 |ref|.  Test infrastructure used as the checker only; None when the
+    checker's library did not travel."""
+    try:
+        import oracle_lib as ol
+    except Exception:  # noqa: BLE001
+        return None
+    if ol.ORACLE is None:
+        return None
+    from nano_vllm_amd import workloads as wl
+
+    g = work.geom
+    seqs = sorted({int(s) for s in seqs})
+    k_host, v_host, tabs, ctx = wl.host_blocks_for(work, seqs, seed_k, seed_v)
+    want = ol.oracle_decode_batch(work.q()[seqs], k_host, v_host, tabs, ctx, g.block_size, g.n_kv_heads)
+    got = np.asarray(out_host)[seqs]
+    err = np.abs(got - want)
+    return {"seqs": seqs, "ctx": [int(c) for c in ctx], "max_abs_err": float(err.max()),
+            "tolerance": "1e-4 + 1e-5*|ref|", "ok": bool((err <= 1e-4 + 1e-5 * np.abs(want)).all()),
+            "against": "oracle/nvk_oracle.c (CPU restatement of attention.hpp:82-159)"}
+
+
+def check_picks(work):
+    """Two sequences of a batch for self_check: the longest and one from the other end of the batch."""
+    longest = int(np.argmax(work.ctx_lens))
+    other = 0 if longest != 0 else work.num_seqs - 1
+    return [longest, other]
 
 
 def cpu_baseline(work, cores):
@@ -174,9 +213,15 @@ def cpu_baseline(work, cores):
     return one, many
 
 
+EXTRA_STEPS = 20    # layer-calls per timed region of an extra workload
+EXTRA_REGIONS = 5   # regions per extra workload: ms_per_step = their median, ms_per_step_min = the fastest
+
+
 def extra_workloads(nv, torch, dev, args):
-    """The other BASELINE.json configs on one GPU, a few steps each (they are parity-test cases first; these
-    lines make their rates visible to whoever runs the default bench): {name: {ms_per_step, GBps, frac, ...}}."""
+    """The other BASELINE.json configs on one GPU (they are parity-test cases first; these lines make their rates
+    visible to whoever runs the default bench): {name: {ms_per_step, GBps, frac, ...}}.  EXTRA_REGIONS timed regions
+    of EXTRA_STEPS layer-calls each: the median region is the number, the fastest is beside it (box-to-box and
+    region-to-region spread is 1-4 % on these)."""
     res = {}
     for name in ("config3", "config4", "5a", "5b"):
         work = make_workload(name)
@@ -192,34 +237,41 @@ def extra_workloads(nv, torch, dev, args):
             torch.cuda.synchronize()
             kname = nv.decode_kernel_name(pool, work.num_seqs, g.n_heads, work.max_ctx, flags, 0)
 
-            def run(warmup, iters, want_attn):
+            def run(warmup, iters, want_attn, replan=1):
                 return nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
-                                       out, flags, 0, warmup, iters, replan_every=1, want_attn=want_attn)
+                                       out, flags, 0, warmup, iters, replan_every=replan, want_attn=want_attn)
 
-            steps = 10
             est_ms, _ = run(3, 3, False)
             # the same clock pre-warm as the headline's (the GPU idled while the host built this workload's tables)
             run(min(2000, int(args.prewarm_ms / max(est_ms, 1e-3)) + 1), 0, False)
-            step_ms, _ = run(0, steps, False)
-            _, attn_ms = run(0, steps, True)
+            regions = [run(0, EXTRA_STEPS, False)[0] for _ in range(EXTRA_REGIONS)]
+            step_ms, step_min = statistics.median(regions), min(regions)
+            kregions = [run(0, EXTRA_STEPS, True)[1] for _ in range(EXTRA_REGIONS)]
+            attn_ms = statistics.median(kregions)
+            out.fill_(float("nan"))
+            run(0, 1, False)
+            checked = self_check(work, out.cpu().numpy(), 1, 2, check_picks(work))
             nbytes = work.algorithmic_bytes()
+            frac = lambda ms: round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             reused = None
             if not uniform_batch:
                 # what an engine does: the plan depends on the lengths only, so it is built once per model step and
                 # serves all of its layer-calls (nvk_plan_build + nvk_decode_planned); here once per 32 launches
-                r_ms, _ = nv.decode_bench(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
-                                          out, flags, 0, 2, 32, replan_every=32, want_attn=False)
-                reused = {"replan_every": 32, "steps": 32, "ms_per_step": round(r_ms, 4),
-                          "GBps": round(nbytes / (r_ms * 1e-3) / 1e9, 1),
-                          "frac": round(nbytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-            res[name] = {"workload": work.name, "steps": steps, "ms_per_step": round(step_ms, 4),
-                         "GBps": round(nbytes / (step_ms * 1e-3) / 1e9, 1),
-                         "frac": round(nbytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "kernel": kname, "kernel_ms": round(attn_ms, 4),
-                         "kernel_frac": round(nbytes / (attn_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "traffic": profiled_traffic(work.name, kname), "algorithmic_bytes": nbytes,
+                rr = [run(2 if i == 0 else 0, 32, False, 32)[0] for i in range(EXTRA_REGIONS)]
+                r_ms = statistics.median(rr)
+                reused = {"replan_every": 32, "steps": 32, "regions": EXTRA_REGIONS, "ms_per_step": round(r_ms, 4),
+                          "ms_per_step_min": round(min(rr), 4),
+                          "GBps": round(nbytes / (r_ms * 1e-3) / 1e9, 1), "frac": frac(r_ms)}
+            traffic, traffic_source = profiled_traffic(work.name, kname)
+            res[name] = {"workload": work.name, "steps": EXTRA_STEPS, "regions": EXTRA_REGIONS,
+                         "ms_per_step": round(step_ms, 4), "ms_per_step_min": round(step_min, 4),
+                         "GBps": round(nbytes / (step_ms * 1e-3) / 1e9, 1), "frac": frac(step_ms),
+                         "frac_best_region": frac(step_min),
+                         "kernel": kname, "kernel_ms": round(attn_ms, 4), "kernel_ms_min": round(min(kregions), 4),
+                         "kernel_frac": frac(attn_ms),
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": nbytes,
                          "plan": "none: uniform lengths" if uniform_batch else "nvk_plan_kernel every layer-call",
-                         "tokens_per_s": round(work.num_seqs / (step_ms * 1e-3), 1)}
+                         "tokens_per_s": round(work.num_seqs / (step_ms * 1e-3), 1), "checked": checked}
             if reused is not None:
                 res[name]["plan_reused_over_32_layer_calls"] = reused
         del q, tabs, ctx, out
@@ -227,44 +279,389 @@ def extra_workloads(nv, torch, dev, args):
     return res
 
 
-class Watchdog:
-    """Bounds the N>1 extras: if they are not finished after `seconds` (a rank stuck in a collective, say), rank 0
-    prints the headline line with what the extras have so far and every rank's process ends with status 0."""
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz)
 
-    def __init__(self, seconds, rank, line, partial):
+
+class HipEvents:
+    """hipEvent timing on a named stream through ctypes (torch.cuda.Event only sees torch's current stream; the
+    library launches on the pool's own stream or on the device's null stream)."""
+
+    def __init__(self):
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        hip.hipEventDestroy.argtypes = [C.c_void_p]
+        self.hip = hip
+        self.e0, self.e1 = C.c_void_p(), C.c_void_p()
+        assert hip.hipEventCreate(C.byref(self.e0)) == 0 and hip.hipEventCreate(C.byref(self.e1)) == 0
+
+    def ms_per_call(self, stream, fn, iters):
+        """iters back-to-back calls of fn() between one event pair on `stream` (an address, 0 = the null stream)."""
+        s = C.c_void_p(stream or None)
+        assert self.hip.hipEventRecord(self.e0, s) == 0
+        for _ in range(iters):
+            fn()
+        assert self.hip.hipEventRecord(self.e1, s) == 0
+        assert self.hip.hipEventSynchronize(self.e1) == 0
+        ms = C.c_float(0.0)
+        assert self.hip.hipEventElapsedTime(C.byref(ms), self.e0, self.e1) == 0
+        return float(ms.value) / iters
+
+    def regions(self, stream, fn, iters, n):
+        got = [self.ms_per_call(stream, fn, iters) for _ in range(n)]
+        return statistics.median(got), min(got)
+
+    def close(self):
+        self.hip.hipEventDestroy(self.e0)
+        self.hip.hipEventDestroy(self.e1)
+
+
+def _tol_ok(got, want):
+    err = np.abs(got - want)
+    return float(err.max()), bool((err <= 1e-4 + 1e-5 * np.abs(want)).all())
+
+
+def prefill_row(nv, torch, dev, ev, args):
+    """SURVEY.md 8f row f3 on the record: paged chunked prefill, 2 prompts x 8192 tokens from position 0, causal,
+    G-llama (ref: experimental/chunked_prefill/model_chunked.hpp:167-224).  Roofline: fp32 MFMA; algorithmic flops
+    4 x keys seen x n_heads x head_dim per query token (QK^T + PV)."""
+    from nano_vllm_amd import workloads as wl
+
+    g = wl.G_LLAMA
+    seqs, chunk = 2, 8192
+    work = wl.uniform_workload("prefill_2x8192", seqs, chunk, g)
+    total = seqs * chunk
+    starts, lens = np.zeros(seqs, np.int32), np.full(seqs, chunk, np.int32)
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim, device=dev.index) as pool:
+        pool.fill_uniform(0, 1, 2)
+        gen = torch.Generator(device=dev).manual_seed(9)
+        q = torch.rand((total, g.n_heads, g.head_dim), generator=gen, device=dev) * 2 - 1
+        out = torch.full_like(q, float("nan"))
+        tabs = torch.from_numpy(work.block_tables).to(dev)
+        torch.cuda.synchronize()
+        run = lambda: nv.prefill_device(pool, 0, g.n_heads, q, tabs, seqs, work.max_blocks, starts, lens, out,
+                                        nv.PREFILL_TILED)
+        run()
+        run()
+        pool.synchronize()
+        ms, ms_min = ev.regions(pool.stream, run, 4, 3)
+        pool.synchronize()
+        checked = None
+        try:
+            import oracle_lib as ol
+            if ol.ORACLE is not None:
+                rows, worst, ok = [(1, chunk - 1), (0, 77)], 0.0, True
+                for s, b in rows:
+                    k_host, v_host, tab, _ = wl.host_blocks_for(work, [s])
+                    want = ol.oracle_paged_attention(q[s * chunk + b].cpu().numpy(), k_host, v_host, tab[0], b + 1,
+                                                     g.block_size, g.head_dim, g.n_heads, g.n_kv_heads)
+                    e, good = _tol_ok(out[s * chunk + b].cpu().numpy(), want)
+                    worst, ok = max(worst, e), ok and good
+                checked = {"rows": [f"seq {s} query {b}" for s, b in rows], "max_abs_err": worst, "ok": ok,
+                           "tolerance": "1e-4 + 1e-5*|ref|",
+                           "against": "oracle/nvk_oracle.c paged_attention with num_tokens = query + 1"}
+        except ImportError:
+            pass
+    keys = seqs * chunk * (chunk + 1) // 2
+    flops = 4.0 * keys * g.n_heads * g.head_dim
+    del q, out, tabs
+    torch.cuda.empty_cache()
+    return {"workload": "paged chunked prefill, 2 prompts x 8192 tokens, causal, 32/8/128, TILED form",
+            "ref": "experimental/chunked_prefill/model_chunked.hpp:167-224", "bound": "mfma",
+            "kernel": "nvk::nvk_prefill_kernel<128>", "calls_per_region": 4, "regions": 3,
+            "kernel_ms": round(ms, 4), "kernel_ms_min": round(ms_min, 4), "algorithmic_flops": flops,
+            "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+            "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "query_tokens_per_s": round(total / (ms * 1e-3), 1), "checked": checked}
+
+
+def projection_rows(nv, torch, dev, ev, args):
+    """SURVEY.md 8f row f1b on the record: the q | k | v projections of a layer's head (ref: include/core/model.hpp:
+    164-166 = Ops::matmul, include/ops/linear.hpp:12-22; BatchOps::batch_matmul, batch_ops.hpp:8-23) at dim 4096 ->
+    4096 + 2 x 1024, ONE launch for the three, for 1 / 16 / 512 activation rows.  Few rows stream the weights once:
+    HBM roofline, algorithmic bytes = the weights; 512 rows: fp32 MFMA roofline, 2 x rows x out x in flops."""
+    D, QD, KD = 4096, 4096, 1024
+    gen = torch.Generator(device=dev).manual_seed(5)
+    sc = 1.0 / float(np.sqrt(D))
+    wq, wk, wv = ((torch.rand((n, D), generator=gen, device=dev) * 2 - 1) * sc for n in (QD, KD, KD))
+    wbytes = (QD + 2 * KD) * D * 4
+    w_host = None
+    res = {}
+    for rows in (1, 16, 512):
+        x = torch.rand((rows, D), generator=gen, device=dev) * 2 - 1
+        q, k, v = (torch.full((rows, n), float("nan"), device=dev) for n in (QD, KD, KD))
+        torch.cuda.synchronize()
+        run = lambda: nv.qkv_project_device(q, k, v, x, None, None, wq, wk, wv, rows, D, QD, KD, device=dev.index)
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        ms, ms_min = ev.regions(0, run, 30, 5)
+        torch.cuda.synchronize()
+        checked = None
+        try:
+            import oracle_lib as ol
+            if ol.ORACLE is not None:
+                if w_host is None:
+                    w_host = [w.cpu().numpy() for w in (wq, wk, wv)]
+                pick = sorted({0, rows - 1})
+                xh = x[pick].cpu().numpy()
+                worst, ok = 0.0, True
+                for got, w in zip((q, k, v), w_host):
+                    e, good = _tol_ok(got[pick].cpu().numpy(), ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, xh, w))
+                    worst, ok = max(worst, e), ok and good
+                checked = {"rows": pick, "max_abs_err": worst, "ok": ok, "tolerance": "1e-4 + 1e-5*|ref|",
+                           "against": "oracle_batch_matmul (pinned bit-exact to Ops::matmul, linear.hpp:12-22)"}
+        except ImportError:
+            pass
+        flops = 2.0 * rows * (QD + 2 * KD) * D
+        row = {"workload": f"q|k|v projection, {rows} row(s), 4096 -> 4096 + 2 x 1024, one launch",
+               "ref": "include/core/model.hpp:164-166, include/ops/linear.hpp:12-22", "calls_per_region": 30,
+               "regions": 5, "ms_per_call": round(ms, 5), "ms_per_call_min": round(ms_min, 5), "checked": checked}
+        if rows <= 32:
+            row.update({"bound": "hbm", "kernel": "nvk::nvk_gemv_kernel" if rows <= 2 else "nvk::nvk_gemm_skinny_kernel",
+                        "algorithmic_bytes": wbytes, "GBps": round(wbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                        "frac": round(wbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+        else:
+            row.update({"bound": "mfma", "kernel": "nvk::nvk_gemm_nt_kernel", "algorithmic_flops": flops,
+                        "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)})
+        res[f"qkv_{rows}row" if rows == 1 else f"qkv_{rows}rows"] = row
+        del x, q, k, v
+    del wq, wk, wv
+    torch.cuda.empty_cache()
+    return res
+
+
+def model_step_rows(nv, torch, dev, args):
+    """SURVEY.md 8f row f4 / the caller of the whole path on the record: LlamaModel::forward (ref: include/core/
+    model.hpp:150-247) as device-resident batched decode steps, TinyLlama geometry (dim 2048, hidden 5632, 22 layers,
+    32/4 heads x 64, vocab 32000; 3.9 GB of fp32 weights, synthetic values in the llama2.c file format), 1 and 64
+    requests at ~1024 context tokens.  A step = embedding .. greedy argmax for every request, wall clock (the call is
+    synchronous: token ids in, next tokens out).  HBM roofline: every layer weight + the classifier once per step,
+    plus the requests' K/V."""
+    import struct
+
+    D, Hd, L, H, KV, V, S = 2048, 5632, 22, 32, 4, 32000, 2048
+    hd = D // H
+    sizes = [V * D, L * D, L * D * H * hd, L * D * KV * hd, L * D * KV * hd, L * H * hd * D, L * D, L * D * Hd,
+             L * Hd * D, L * D * Hd, D]  # model.hpp:322-347's order; no separate classifier: shared with the embedding
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(tmpdir, f"nvk_bench_tinyllama_{os.getpid()}.bin")
+    rng = np.random.default_rng(1)
+    tile = rng.random(1 << 22, dtype=np.float32) - np.float32(0.5)
+    try:
+        with open(path, "wb") as fh:
+            fh.write(struct.pack("7i", D, Hd, L, H, KV, V, S))
+            for i, n in enumerate(sizes):
+                norm = i in (1, 6, 10)
+                w = (1.0 + 0.1 * tile) if norm else tile * np.float32(2.0 / np.sqrt(D) if i else 2.0)
+                buf = w.astype(np.float32).tobytes()
+                left = n * 4
+                while left:
+                    m = min(left, len(buf))
+                    fh.write(buf[:m])
+                    left -= m
+        ctx, steps, bs = 1024, 16, 16
+        blocks = 64 * ((ctx + 2 * steps + bs) // bs + 1)
+        res = {}
+        with nv.LlamaModel(path, bs, blocks, max_seqs=64, device=dev.index) as m:
+            os.unlink(path)  # resident in HBM now
+            for n_req in (1, 64):
+                ids = list(range(n_req))
+                for r in ids:
+                    m.add_request(r)
+                fed = 0
+                while fed < ctx:
+                    c = min(512, ctx - fed)
+                    nxt, _ = m.step_chunks(ids, [rng.integers(3, V, size=c).tolist() for _ in ids])
+                    fed += c
+                for _ in range(3):
+                    nxt, _ = m.step(ids, nxt.tolist())
+                times = []
+                for _ in range(steps):
+                    t0 = time.perf_counter()
+                    nxt, _ = m.step(ids, nxt.tolist())
+                    times.append(time.perf_counter() - t0)
+                for r in ids:
+                    m.finish_request(r)
+                dt = statistics.median(times)
+                weight_bytes = 4 * (sum(sizes) - V * D) + 4 * V * D  # layers + final norm, and the classifier (= embedding rows)
+                kv_bytes = int(n_req * L * 2 * (ctx + 3 + steps / 2) * KV * hd * 4)
+                res[f"model_step_tinyllama_b{n_req}"] = {
+                    "workload": f"LlamaModel::forward as one batched decode step, TinyLlama geometry, {n_req} request(s) "
+                                f"at ~{ctx} context tokens, greedy",
+                    "ref": "include/core/model.hpp:150-247", "bound": "hbm", "steps": steps,
+                    "ms_per_step": round(dt * 1e3, 4), "ms_per_step_min": round(min(times) * 1e3, 4),
+                    "tokens_per_s": round(n_req / dt, 1),
+                    "algorithmic_bytes": weight_bytes + kv_bytes, "weight_bytes": weight_bytes, "kv_bytes": kv_bytes,
+                    "GBps": round((weight_bytes + kv_bytes) / dt / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                    "frac": round((weight_bytes + kv_bytes) / dt / 1e9 / HBM_PEAK_GBPS, 4),
+                    "checked": None, "parity": "tests/test_gpu_model_stream.py (reference token streams, fixture F4)"}
+        return res
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+def f_row_workloads(nv, torch, dev, args):
+    """SURVEY.md 8f's rows on the driver's record (N = 1 extras, headline untouched): prefill, the projections, the model
+    step.  A row that fails is reported as {"error": ...} and the line's top-level `extras_failed` says so."""
+    ev = HipEvents()
+    res = {}
+    for name, fn in (("prefill_2x8192", lambda: {"prefill_2x8192": prefill_row(nv, torch, dev, ev, args)}),
+                     ("qkv", lambda: projection_rows(nv, torch, dev, ev, args)),
+                     ("model_step_tinyllama", lambda: model_step_rows(nv, torch, dev, args))):
+        try:
+            res.update(fn())
+        except Exception as exc:  # noqa: BLE001 -- reported in the line, and the exit status says so
+            res[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    ev.close()
+    return res
+
+
+class Watchdog:
+    """Bounds the shutdown handshake of an N > 1 run (dist.destroy_process_group can wait for a peer for ever).  By the
+    time it is armed every number has been printed and checked and this process has no GPU work outstanding; if the
+    handshake does not come back within `seconds` the process says so on stderr and leaves with `status`."""
+
+    def __init__(self, seconds, what, status=0):
         import threading
 
-        self._lock = threading.Lock()
-        self._state = "running"
         self._done = threading.Event()
 
         def dog():
             if self._done.wait(seconds):
                 return
-            with self._lock:
-                if self._state != "running":
-                    return
-                self._state = "timed out"
-            if line is not None:
-                got = dict(partial)
-                got["error"] = f"extras not finished after {seconds:.0f} s on rank {rank}: line printed without the rest"
-                line["multi_gpu_workloads"] = got
-                print(json.dumps(line), flush=True)
-            os._exit(0)
+            print(f"bench.py: {what} not finished after {seconds:.0f} s; leaving with status {status}", file=sys.stderr,
+                  flush=True)
+            os._exit(status)
 
         threading.Thread(target=dog, daemon=True).start()
 
     def finish(self):
-        """True: the extras came back in time and the caller prints; False: the watchdog has taken over."""
-        with self._lock:
-            if self._state != "running":
-                return False
-            self._state = "finished"
         self._done.set()
-        return True
 
 
-def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red_dev, barrier, res):
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the ranks ourselves, as the child process
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` (one process per GPU),
+    BEFORE this process has imported torch or touched the GPU; its output is ours and so is its exit status."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def extras_in_children(dist, args, rank, world, local_rank):
+    """The N > 1 extras (configs[4]) run in a FRESH process per rank, not in the process that holds the headline: a rank
+    stuck in a collective or a hung kernel is then a child this rank can end (by its pid) while staying healthy itself.
+    Rank 0 picks a free rendezvous port for the children; every rank starts `bench.py --extras-child` with its own
+    RANK / LOCAL_RANK / WORLD_SIZE and waits for it at most --extra-timeout seconds.  Returns (results or None,
+    error text or None) on rank 0, (None, error) elsewhere."""
+    box = [free_port() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    out_path = os.path.join(tempfile.gettempdir(), f"nvk_bench_extras_{box[0]}_{rank}.json")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}  # (the agent's store is not theirs)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(box[0])})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--extras-child", out_path, "--gpus", str(world), "--backend",
+           args.backend, "--prewarm-ms", str(args.prewarm_ms)]
+    error = None
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL)
+    try:
+        rc = proc.wait(timeout=args.extra_timeout)
+        if rc != 0:
+            error = f"extras child of rank {rank} ended with status {rc}"
+    except subprocess.TimeoutExpired:
+        proc.kill()  # this rank's own child, by pid
+        proc.wait()
+        error = f"extras not finished after {args.extra_timeout:.0f} s on rank {rank}: child ended, partial results kept"
+    got = None
+    if rank == 0:
+        try:
+            with open(out_path) as fh:
+                got = json.load(fh)
+        except (OSError, ValueError):
+            got = None
+    try:
+        os.unlink(out_path)
+    except OSError:
+        pass
+    # one verdict for the job: any rank's failure is the job's
+    errs = [None] * world
+    dist.all_gather_object(errs, error)
+    errs = [e for e in errs if e]
+    return got, ("; ".join(errs)[:600] if errs else None)
+
+
+def extras_child_main(args):
+    """`bench.py --extras-child PATH`: one rank of the N > 1 extras in its own process group.  Rank 0 rewrites PATH
+    (atomically) after every finished workload, so whatever was done before a time-out is kept."""
+    nv, torch, dist, rank, local_rank, world, dev, red_dev, barrier = init_ranks(args)
+    res = {}
+
+    def publish():
+        if rank == 0:
+            with open(args.extras_child + ".tmp", "w") as fh:
+                json.dump(res, fh)
+            os.replace(args.extras_child + ".tmp", args.extras_child)
+
+    try:
+        multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red_dev, barrier, res, publish)
+    except Exception as exc:  # noqa: BLE001 -- recorded, and this child's status says so
+        res["error"] = f"{type(exc).__name__}: {exc}"[:300]
+        publish()
+        os._exit(3)  # (peers may be waiting in a collective: no handshake)
+    publish()
+    dog = Watchdog(20.0, "extras child: destroy_process_group")
+    dist.destroy_process_group()
+    dog.finish()
+
+
+def init_ranks(args):
+    """torch + the library + this process's place in the job: RANK / LOCAL_RANK / WORLD_SIZE from the environment
+    (torch.distributed.run's), one process per GPU, RCCL ("nccl") or gloo (rehearsal: ranks share GPUs)."""
+    import torch
+    import nano_vllm_amd as nv
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if nv.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()  # rehearsal: more ranks than GPUs
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the timing reduction lives
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    return nv, torch, dist, rank, local_rank, world, dev, red_dev, barrier
+
+
+def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red_dev, barrier, res, publish):
     """BASELINE.json configs[4] across the ranks of this launch; fills `res` key by key (all ranks; rank 0's is printed).
 
     5a / 5b: rank r decodes sequences [512 r, 512 (r + 1)) of the 512 x world from a pool of its own: weak scaling, no
@@ -274,7 +671,7 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
     from nano_vllm_amd import sharding as sh
     from nano_vllm_amd import workloads as wl
 
-    steps = 10
+    steps = EXTRA_STEPS
 
     def reduce_max(*vals):
         t = torch.tensor(list(vals), dtype=torch.float64, device=red_dev)
@@ -311,6 +708,9 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
             wall = time.perf_counter() - t0
             barrier()
             _, attn_ms = run(0, steps, True)
+            out.fill_(float("nan"))
+            run(0, 1, False)
+            checked = self_check(work, out.cpu().numpy(), 1 + 16 * rank, 2 + 16 * rank, check_picks(work))  # rank 0's is printed
             # every rank's batch has its own lengths (5a): the job's bytes are the sum over ranks
             tot = torch.tensor([float(work.algorithmic_bytes()), float(work.num_seqs)], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -321,7 +721,8 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
                          "GBps": round(float(tot[0]) / (ms * 1e-3) / 1e9, 1),
                          "frac_per_gpu": round(float(tot[0]) / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "slowest_kernel_ms": round(attn_ms, 4), "sequences": int(tot[1]),
-                         "tokens_per_s": round(float(tot[1]) / (ms * 1e-3), 1)}
+                         "tokens_per_s": round(float(tot[1]) / (ms * 1e-3), 1), "checked_on_rank0": checked}
+            publish()
             del q, tabs, ctx, out
         torch.cuda.empty_cache()
 
@@ -329,6 +730,7 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
     gf = full.geom
     if gf.n_kv_heads % world != 0:
         res["5b_head_sharded"] = {"skipped": f"{world} ranks do not divide {gf.n_kv_heads} kv-heads"}
+        publish()
         return
     hs = sh.HeadShard(rank, world, gf.n_heads, gf.n_kv_heads)
     g = wl.Geometry(hs.local_heads, hs.local_kv_heads, gf.head_dim, gf.block_size)
@@ -341,6 +743,7 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
         wall, step_ms, attn_ms = head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, 0, steps, 3,
                                                   args.backend, rank, world, local_rank, dev, barrier)
         wall, step_ms, attn_ms = reduce_max(wall, step_ms, attn_ms)
+        checked = self_check(work, out.cpu().numpy(), 1 + 16 * rank, 2 + 16 * rank, check_picks(work))  # this rank's heads
         ms = wall * 1e3 / steps
         nbytes = work.algorithmic_bytes()  # this rank's heads of the whole batch
         shard_bytes = work.num_seqs * g.n_heads * g.head_dim * 4
@@ -354,7 +757,8 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
             "GBps": round(nbytes * world / (ms * 1e-3) / 1e9, 1),
             "frac_per_gpu": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "slowest_kernel_ms": round(attn_ms, 4), "sequences": work.num_seqs,
-            "tokens_per_s": round(work.num_seqs / (ms * 1e-3), 1)}
+            "tokens_per_s": round(work.num_seqs / (ms * 1e-3), 1), "checked_on_rank0": checked}
+        publish()
         del q, tabs, ctx, out
     torch.cuda.empty_cache()
 
@@ -475,29 +879,21 @@ def main():
                          "before the headline line is printed without them")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no per-kernel event pairs inside the timed region (roofline from step time)")
+    ap.add_argument("--no-frows", action="store_true",
+                    help="N=1 only: skip SURVEY.md 8f's rows (prefill, projections, model step) timed after the extras")
+    ap.add_argument("--extras-child", default=None, metavar="PATH",
+                    help="internal: run one rank of the N>1 extras in this (fresh) process and leave rank 0's results "
+                         "at PATH; started by the rank processes themselves, see extras_in_children()")
     args = ap.parse_args()
 
-    import torch
-    import nano_vllm_amd as nv
+    if args.extras_child is not None:
+        return extras_child_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` as the driver's N = 1 command is shaped: start the ranks ourselves (a child process,
+        # before torch is imported or the GPU touched) and pass its line and status on
+        return self_launch(args.gpus, sys.argv[1:])
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if nv.device_count() < 1 or not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if args.backend == "gloo":
-        local_rank %= torch.cuda.device_count()  # rehearsal: more ranks than GPUs
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
-    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the timing reduction lives
+    nv, torch, dist, rank, local_rank, world, dev, red_dev, barrier = init_ranks(args)
 
     work = make_workload(args.workload, 0 if args.strong else rank, args.geom)
     g = work.geom
@@ -524,10 +920,6 @@ def main():
     planning = ("none: uniform lengths, natural chunk order" if flags & nv.UNIFORM else
                 "none: lengths read by the decode kernel, natural chunk order" if flags & nv.NO_PLAN else
                 f"nvk_plan_kernel, rebuilt every {args.replan} layer-call(s)")
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
     if args.shard == "heads":
         # head-group variant: this rank's pool holds n_kv_heads/world kv-heads of every sequence
@@ -574,6 +966,7 @@ def main():
             attn_ms = step_ms
         else:
             _, attn_ms = run(0, args.steps, True)
+        out_host = out.cpu().numpy()  # what the last of those launches left in HBM (layer 0's slab)
         if rotate > 1:  # the same batch over `rotate` different slabs in turn: nothing can be served from the Infinity Cache
             run(rotate, 0, False, rotate)
             r_step, _ = run(0, args.steps, False, rotate)
@@ -584,6 +977,7 @@ def main():
         wall, step_ms, attn_ms = head_sharded_leg(nv, torch, dist if world > 1 else None, hs, pool, work, q, tabs, ctx, out,
                                                   flags, args.chunk, args.steps, args.warmup, args.backend, rank, world,
                                                   local_rank, dev, barrier)
+        out_host = out.cpu().numpy()
 
     if world > 1:
         t = torch.tensor([wall, step_ms, attn_ms], dtype=torch.float64, device=red_dev)
@@ -591,6 +985,7 @@ def main():
         wall, step_ms, attn_ms = (float(x) for x in t.tolist())
 
     line = None
+    status = 0
     if rank == 0:
         nbytes = work.algorithmic_bytes()  # per rank, per layer-call
         ms_per_step = wall * 1e3 / args.steps
@@ -600,6 +995,8 @@ def main():
         seqs_all = work.num_seqs * (world if args.shard == "seq" else 1)  # head shards all hold the same batch
         if whole_bytes is not None:
             seqs_all = make_workload(args.workload, 0, args.geom).num_seqs
+        traffic, traffic_source = (profiled_traffic(work.name, kernel_name) if args.mode == "auto" and args.chunk == 0
+                                   else (None, None))
         line = {
             "metric": "paged_attn_decode_achieved_hbm_GBps",
             "value": round(value, 1),
@@ -627,12 +1024,15 @@ def main():
             "event_ms_per_step": round(step_ms, 4),
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": profiled_traffic(work.name, kernel_name) if args.mode == "auto" and args.chunk == 0
-                         else None,
+                         "traffic": traffic,
+                         "traffic_source": (f"{traffic_source}: rocprofv3 --pmc passes over this workload and kernel, "
+                                            "committed; not measured in this run") if traffic_source else None,
                          "kernel_ms": round(attn_ms, 4), "algorithmic_bytes": nbytes,
                          "kernel_events": ("none: step time" if args.no_kernel_events else
                                            f"HIP event pair around each of {args.steps} launches on the launch stream, "
                                            "a second pass right after the timed region")},
+            # rows of `out` as the last timed launch left them, against the CPU checker (rank 0's batch)
+            "checked": self_check(work, out_host, 1 + 16 * rank, 2 + 16 * rank, check_picks(work)),
         }
         if rotated is not None:
             r_step, r_attn = rotated
@@ -640,10 +1040,16 @@ def main():
                                "ms_per_step": round(r_step, 4), "GBps": round(nbytes / (r_step * 1e-3) / 1e9, 1),
                                "kernel_ms": round(r_attn, 4),
                                "kernel_frac": round(nbytes / (r_attn * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-        if world == 1 and args.shard == "seq" and not args.no_extra and args.workload == "config2" and args.geom == "llama":
+        default_run = args.shard == "seq" and args.workload == "config2" and args.geom == "llama" and not args.strong
+        if world == 1 and default_run and not (args.no_extra and args.no_frows):
             pool.close()
             pool = None
-            line["workloads"] = extra_workloads(nv, torch, dev, args)
+            del q, tabs, ctx, out
+            torch.cuda.empty_cache()
+            if not args.no_extra:
+                line["workloads"] = extra_workloads(nv, torch, dev, args)
+            if not args.no_frows:
+                line["f_rows"] = f_row_workloads(nv, torch, dev, args)
         if world == 1 and not args.no_cpu:
             cores = min(16, os.cpu_count() or 1)
             one, many = cpu_baseline(work, cores)
@@ -654,38 +1060,61 @@ def main():
 
     # N > 1, default launch: BASELINE.json configs[4] while all ranks are here -- 5a and 5b sequence-sharded (rank r's
     # 512 of the 512 x N sequences, no collective) and 5b's batch head-sharded (every rank a kv-head group of ALL
-    # 512 x N sequences, one RCCL all-gather of out per layer-call through nvk_shard_*).  Extra keys of the same line;
-    # a watchdog prints the headline without them if a rank fails to come back.
-    multi = None
+    # 512 x N sequences, one RCCL all-gather of out per layer-call through nvk_shard_*).  Extra keys of the same line,
+    # measured by a fresh child process per rank (extras_in_children): the headline's processes stay healthy whatever
+    # happens there, and say so in `extras_failed` / `multi_gpu_workloads.error`.
     if (world > 1 and args.shard == "seq" and not args.strong and not args.no_extra and args.workload == "config2"
             and args.geom == "llama"):
         pool.close()
         pool = None
         del q, tabs, ctx, out
         torch.cuda.empty_cache()
-        multi = {}
-        dog = Watchdog(args.extra_timeout, rank, line if rank == 0 else None, multi)
-        try:
-            multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red_dev, barrier, multi)
-        except Exception as exc:  # noqa: BLE001 -- the headline must still be printed
-            multi["error"] = f"{type(exc).__name__}: {exc}"[:300]
-        if not dog.finish():
-            return  # the watchdog is printing (or has printed) the line and ends the process
+        multi, error = extras_in_children(dist, args, rank, world, local_rank)
         if rank == 0:
+            multi = multi if isinstance(multi, dict) else {}
+            if error and "error" not in multi:
+                multi["error"] = error
             line["multi_gpu_workloads"] = multi
+            line["extras_failed"] = bool(error) or "error" in multi
+
     if rank == 0:
+        def bad(node):  # any {"ok": False} check or {"error": ...} row below `node`
+            if isinstance(node, dict):
+                if node.get("ok") is False:
+                    return "check"
+                if "error" in node:
+                    return "error"
+                for v in node.values():
+                    got = bad(v)
+                    if got:
+                        return got
+            return None
+
+        line.setdefault("extras_failed", False)
+        for key in ("workloads", "f_rows"):
+            if bad(line.get(key)) == "error":
+                line["extras_failed"] = True
+        failed_check = (line["checked"] or {}).get("ok") is False or any(
+            bad(line.get(key)) == "check" for key in ("workloads", "f_rows", "multi_gpu_workloads"))
+        line["check_failed"] = failed_check
         print(json.dumps(line), flush=True)
+        if line["extras_failed"]:
+            print("bench.py: an extra workload failed (see extras_failed and the error keys of the line); the headline "
+                  "number stands", file=sys.stderr, flush=True)
+        if failed_check:
+            print("bench.py: a timed launch's output differs from the CPU checker: the line is NOT a valid measurement",
+                  file=sys.stderr, flush=True)
+            status = 4
 
     if pool is not None:
         pool.close()
     if world > 1:
         sys.stdout.flush()
-        if multi is not None and "error" in multi:
-            os._exit(0)  # ranks may have left the extras at different points: no further collective is safe
-        dog = Watchdog(20.0, rank, None, {})  # (a peer that left that way never answers the shutdown handshake)
+        dog = Watchdog(20.0, "destroy_process_group", status)
         dist.destroy_process_group()
         dog.finish()
+    return status
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -180,11 +180,11 @@ def config5b(num_seqs: int = 512, geom: Geometry = G_LLAMA) -> Workload:
     return uniform_workload(f"decode_{num_seqs}x2048_uniform", num_seqs, 2048, geom)
 
 
-def host_blocks_for(work: Workload, seqs: List[int]):
+def host_blocks_for(work: Workload, seqs: List[int], seed_k: int = SEED_K, seed_v: int = SEED_V):
     """Compact host copies of just the blocks the given sequences touch.
 
     Returns (k_pool, v_pool, tables, ctx) where the pools hold the touched blocks
-    back to back (values exactly as ``fill_uniform`` leaves them in the full
+    back to back (values exactly as ``fill_uniform(seed_k, seed_v)`` leaves them in the full
     device pool) and ``tables`` is remapped onto them -- what a CPU checker needs
     to verify sequences of a pool too large to materialise on the host."""
     g = work.geom
@@ -199,8 +199,8 @@ def host_blocks_for(work: Workload, seqs: List[int]):
     k_pool = np.empty((max(len(ids), 1), g.block_size, g.n_kv_heads, g.head_dim), np.float32)
     v_pool = np.empty_like(k_pool)
     for i, pb in enumerate(ids):
-        k_pool[i] = uniform_block(SEED_K, pb, bf).reshape(k_pool.shape[1:])
-        v_pool[i] = uniform_block(SEED_V, pb, bf).reshape(k_pool.shape[1:])
+        k_pool[i] = uniform_block(seed_k, pb, bf).reshape(k_pool.shape[1:])
+        v_pool[i] = uniform_block(seed_v, pb, bf).reshape(k_pool.shape[1:])
     tables = np.zeros((len(seqs), work.max_blocks), np.int32)
     for r, s in enumerate(seqs):
         row = work.blocks_of(s)
