@@ -12,9 +12,12 @@
  * Threading: a pool is thread-compatible (external synchronisation per pool);
  * distinct pools (one per GPU) may be driven from different host threads.
  * Streams: the split-K partials of decode and prefill calls on one pool live
- * in ONE workspace owned by the pool, so launches on a pool must be ordered
- * with respect to each other (one stream, or events between streams); pools
- * are independent of each other.
+ * in ONE workspace owned by the pool -- and so do the arrival counters of the
+ * in-kernel combine, which every launch finds at zero and leaves at zero -- so
+ * launches on a pool must be ordered with respect to each other (one stream,
+ * or events between streams): two decode launches of one pool that overlap in
+ * time would share partials and counters, and rows of `out` could stay
+ * unwritten.  Pools are independent of each other.
  * nvk_bm_* is safe exactly where the reference's BlockManager is: the
  * *_for_request / *_safe entry points lock, the plain ones do not.
  */
@@ -52,6 +55,10 @@ extern "C" {
  * length that order is the natural one and the plan kernel is skipped: */
 #define NVK_DECODE_UNIFORM 0x400 /* every sequence holds exactly max_ctx tokens; ctx_lens_dev may be NULL   */
 #define NVK_DECODE_NO_PLAN 0x800 /* ragged lengths, read by the decode kernel itself; natural chunk order   */
+/* A plan built with NVK_DECODE_NO_PLAN holds no copy of the lengths: it keeps the caller's ctx_lens_dev POINTER, and
+ * every nvk_decode_planned (and combine kernel) of that plan reads the array again.  The array must stay allocated and
+ * unchanged for as long as the plan is used -- hipGraph replays of such launches included.  (A plan built without the
+ * modifier is self-contained: its work list was computed from the lengths at build time.) */
 /* GQA groups of 5..16 q-heads over head_dim 64 / 128 run their dot products on fp32 MFMA tiles (exact fp32, another
  * order of sums than the vector kernel).  This modifier keeps such a launch on the vector kernel (A/B, tests). */
 #define NVK_DECODE_VECTOR_ONLY 0x1000
@@ -284,6 +291,8 @@ int nvk_pool_reserve_workspace(nvk_pool *pool, int num_seqs, int n_heads, int ma
  * (positions and block tables shared by all layers, include/core/model.hpp:157-221)
  * plays on the CPU.  Build and use a plan on the same stream (or order the
  * streams yourself).  nvk_plan_build may allocate; nvk_decode_planned never does.
+ * With NVK_DECODE_NO_PLAN in `flags` the plan refers to ctx_lens_dev instead of
+ * copying it: see the lifetime note at that flag.
  * ctx_lens_dev is a device pointer.  out4 = {chunk_tokens, max_chunks,
  * workgroup bound, kv-heads per workgroup}. */
 int nvk_plan_create(nvk_pool *pool, nvk_plan **out_plan);

@@ -374,6 +374,12 @@ __device__ __forceinline__ void merge_chunks(const float *ws_o, const float *ws_
 }
 
 // ---- split-K combine by the workgroup that arrives last (cdna_hip_programming.md, Guideline 16) ----
+// The ordering below is spelled in gfx950's own terms: partials stored with the sc1 bit (aux 16 = write-through to
+// memory on gfx940+; the same bit means something else on gfx90a), drained with s_waitcnt, a relaxed agent-scope
+// arrival, one acquire fence on the last arriver.  On another target it would silently lose its meaning:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "nvk_kernels.hip.h: the in-kernel split-K combine is written for gfx950 (sc1 write-through stores); build with --offload-arch=gfx950"
+#endif
 // Called by EVERY wave of a workgroup whose chunk's partial has just been stored write-through (sc1).  Every
 // storing wave drains its stores, the workgroup meets, ONE lane adds the arrival (agent scope).  Whoever draws
 // nch - 1 knows every chunk of the sequence has been written through: one agent-scope acquire (drops this CU's
@@ -1145,11 +1151,13 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
 
-    // token-split: the parts of one kv-head meet in LDS, record = (m, l, -, -, o[HD]) per (wave, head)
+    // token-split: the parts of one kv-head meet in LDS, record = (m, l, -, -, o[HD]) per (wave, head) of parts
+    // 1 .. parts - 1 (part 0 merges from its registers: no record; make_shape sizes the area for parts - 1)
     if (parts > 1) {
         float *s_mrg = reinterpret_cast<float *>(s_tab + p.merge_off);
+        auto   rec_of = [&](int w) { return s_mrg + ((w - p.kv_waves) * kv_mul + c16) * kRec; }; // w >= kv_waves
         if (part > 0 && head_live) {
-            float *rec = s_mrg + (wave * kv_mul + c16) * kRec;
+            float *rec = rec_of(wave);
             if (q4 == 0)
                 rec[0] = m_run, rec[1] = l_run;
 #pragma unroll
@@ -1165,7 +1173,7 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
         if (part == 0 && head_live) {
             float mw = m_run;
             for (int q = 1; q < parts; q++)
-                mw = fmaxf(mw, s_mrg[((q * p.kv_waves + wave) * kv_mul + c16) * kRec]);
+                mw = fmaxf(mw, rec_of(q * p.kv_waves + wave)[0]);
             const float f0 = fast_exp2(m_run - mw);
             float       lw = l_run * f0;
 #pragma unroll
@@ -1174,7 +1182,7 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
                 for (int c = 0; c < 4; c++)
                     oacc[j][c] *= f0;
             for (int q = 1; q < parts; q++) {
-                const float *rec = s_mrg + ((q * p.kv_waves + wave) * kv_mul + c16) * kRec;
+                const float *rec = rec_of(q * p.kv_waves + wave);
                 const float  f   = fast_exp2(rec[0] - mw);
                 lw               = fmaf(rec[1], f, lw);
 #pragma unroll

@@ -306,6 +306,7 @@ bool decode_flags_ok(int flags)
 }
 
 constexpr int kMaxTableSliceEntries = 8192; // 32 KiB of LDS per workgroup at most
+constexpr int kLdsPerLaunch = 64 * 1024;    // dynamic LDS a launch may ask for without hipFuncSetAttribute
 
 int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens,
                LaunchShape *plan)
@@ -350,8 +351,20 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
 
     const int step    = plan->mfma ? 16 : nvk::step_tokens(plan->vpl, plan->qpk) / plan->kpw;
     const int ctx_cap = round_up(std::max(max_ctx, 1), step);
-    // a workgroup stages its chunk's table slice in LDS: bound the chunk by that
-    const long long slice_cap = (long long)kMaxTableSliceEntries * pool->block_size / step * step;
+    // token-split workgroups keep one (m, l, o) record per wave and q-head in LDS behind the table slice (the MFMA
+    // kernel's part 0 merges from registers and writes none: parts - 1 records per kv-head there)
+    size_t merge_bytes = 0;
+    if (plan->parts > 1)
+        merge_bytes = (size_t)plan->waves * (plan->mfma ? plan->parts - 1 : plan->parts) * plan->kpw * plan->qpk
+                      * (4 + plan->vpl * 64) * sizeof(float);
+    // a workgroup stages its chunk's table slice in LDS: bound the chunk by that, and slice + merge area by the
+    // 64 KiB a launch gets without opting in (16 q-heads x 128 floats x 7 records are 58 KiB on their own)
+    const long long slice_entries =
+        std::min<long long>(kMaxTableSliceEntries, ((long long)kLdsPerLaunch - (long long)merge_bytes) / 4 - 8);
+    if (slice_entries < 4)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "decode: %zu bytes of token-split records do not fit the workgroup's LDS",
+                         merge_bytes);
+    const long long slice_cap = std::max<long long>(step, slice_entries * pool->block_size / step * step);
 
     long long chunk = 0;
     if (flags == NVK_DECODE_SINGLE_PASS) {
@@ -396,9 +409,10 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
                  && plan->kv_groups == 1 && plan->parts == 1 && plan->chunk_tokens >= NVK_WIDE_MIN_CHUNK
                  && plan->chunk_tokens % 16 == 0;
     plan->merge_off    = (plan->chunk_tokens / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
-    plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int);
-    if (plan->parts > 1)
-        plan->lds_bytes += (size_t)plan->waves * plan->parts * plan->kpw * plan->qpk * (4 + plan->vpl * 64) * sizeof(float);
+    plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int) + merge_bytes;
+    if (plan->lds_bytes > (size_t)kLdsPerLaunch) // (cannot happen: the chunk was bounded for it above)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "decode: the launch needs %zu bytes of LDS, more than %d", plan->lds_bytes,
+                         kLdsPerLaunch);
     plan->qgroups            = plan->kv_groups * (kv_mul / plan->qpk);
     plan->force_serial_merge = (mods & NVK_DECODE_MERGE_SEPARATE) != 0;
     plan->fuse_merge         = plan->max_chunks > 1 && !plan->force_serial_merge

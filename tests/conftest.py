@@ -19,6 +19,9 @@ def pytest_collection_modifyitems(config, items):
     import nano_vllm_amd
 
     if nano_vllm_amd.device_count() > 0:
+        # a GPU run gets its tree from the build container, where oracle/_ref/ was built from the reference: the
+        # engine drop-in tests then FAIL rather than skip when that library did not travel (NVK_EXPECT_REF=0 opts out)
+        os.environ.setdefault("NVK_EXPECT_REF", "1")
         return
     skip = pytest.mark.skip(reason="no HIP device visible")
     for item in items:

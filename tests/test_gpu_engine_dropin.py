@@ -13,6 +13,16 @@ nvk_paged_attention).  The library only exists where it was built from
 Pass = teacher-forced logits within tolerance of the recorded reference run,
 identical argmax per step, identical greedy token stream, identical per-layer
 block tables (golden F4/F5, tests/golden/tiny_llama_stream.npz).
+
+Tolerances: the bars in this file (5e-4 + 1e-4 |ref| on the last layer's attention output, 2e-3 + 1e-4 |ref| on the
+logits) are NOT north_star's per-call bar.  They are a stated deviation for quantities that sit behind L layers of
+fp32 GEMVs whose inputs already differ in the last bits; what they guard is exact: the argmax at every position, the
+greedy stream and the block tables.  The authoritative bar for the path itself, 1e-4 + 1e-5 |ref| per attention call,
+is held where a single call can be compared: tests/test_gpu_attention.py.
+
+The library is a built file that has to travel with the tree: with NVK_EXPECT_REF=1 (tests/conftest.py sets it
+whenever a GPU is visible) its absence FAILS these tests instead of skipping them, so BASELINE.json configs[0] cannot
+go untested without anyone noticing.  NVK_EXPECT_REF=0 restores the skip (a checkout built without /root/reference).
 """
 import ctypes as C
 import os
@@ -36,7 +46,10 @@ def _p(a):
 @pytest.fixture(scope="module")
 def engine():
     if not os.path.exists(DROPIN_PATH):
-        pytest.skip("oracle/_ref/libnvk_ref_dropin.so was not built (needs /root/reference at build time)")
+        why = "oracle/_ref/libnvk_ref_dropin.so was not built (needs /root/reference at build time: make ref)"
+        if os.environ.get("NVK_EXPECT_REF", "0") == "1":
+            pytest.fail(why + "; NVK_EXPECT_REF=1 says it should have travelled with the tree")
+        pytest.skip(why)
     return ol._load_ref(DROPIN_PATH)
 
 

@@ -14,9 +14,12 @@ from test_gpu_attention import assert_close, pool_from_host
 
 pytestmark = pytest.mark.gpu
 
-# (n_heads, n_kv_heads, head_dim, block_size): token-split parts 8 / 4 / 2 / 1, two kv-head groups, odd group sizes
+# (n_heads, n_kv_heads, head_dim, block_size): token-split parts 8 / 4 / 2 / 1, two kv-head groups, odd group sizes;
+# the last three are the head-sharded ranks of a 128-head / 8-kv-head model: 16 q-heads per kv-head x 128 floats, where
+# the token-split records are 58 KiB (7 of them), 50 KiB and 33 KiB of the workgroup's LDS
 GEOMS = [(8, 1, 128, 16), (16, 2, 64, 16), (32, 4, 128, 16), (32, 4, 64, 16), (64, 8, 128, 8), (96, 12, 64, 32),
-         (5, 1, 64, 4), (14, 2, 128, 16), (48, 3, 128, 16), (80, 16, 64, 16)]
+         (5, 1, 64, 4), (14, 2, 128, 16), (48, 3, 128, 16), (80, 16, 64, 16), (16, 1, 128, 16), (32, 2, 128, 16),
+         (64, 4, 128, 16)]
 
 
 @pytest.mark.parametrize("geom", GEOMS, ids=[f"H{g[0]}_KV{g[1]}_hd{g[2]}_bs{g[3]}" for g in GEOMS])
@@ -36,6 +39,21 @@ def test_mfma_decode_against_checker_and_vector_kernel(geom):
             vec = nv.decode(pool, 0, q, work.block_tables, ctx, flags | nv.VECTOR_ONLY, chunk)
             assert_close(vec, want, f"{geom} vector kernel flags=0x{flags:x} chunk={chunk}")
         assert not got[6].any()  # ctx 0 -> zero row (attention.hpp:98)
+
+
+def test_mfma_token_split_records_and_a_long_table_slice_share_the_lds():
+    """16 q-heads x 128 floats x 7 token-split records leave 6 KiB of the launch's 64 KiB for the block-table slice:
+    a one-chunk request over 30 000 tokens is cut to what fits (and combined) instead of overrunning the LDS."""
+    g = wl.Geometry(16, 1, 128, 16)
+    ctx = np.array([30000, 5], np.int32)
+    work = wl.fragmented_workload("mfma_lds", ctx, g, perm_seed=5)
+    q = work.q() * np.float32(2.0)
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, [0, 1])
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, g.block_size, g.n_kv_heads, n_threads=2)
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for flags, chunk in ((nv.SINGLE_PASS, 0), (nv.AUTO, 0), (nv.SPLIT_K, 28000)):
+            assert_close(nv.decode(pool, 0, q, work.block_tables, ctx, flags, chunk), want, f"flags={flags} chunk={chunk}")
 
 
 def test_mfma_decode_rescale_and_reference_floor():

@@ -5,7 +5,11 @@ attention), nvk_batch_matmul_device for wo / w_gate / w_up / w_down / lm_head, n
 FFN and final norms.  Only the residual adds and SwiGLU (elementwise, model.hpp:227-239) run in numpy here.
 
 Bar: identical greedy streams and teacher-forced argmax (BASELINE.json north_star: "identical greedy-decoded token
-streams"); logits within 2e-3 + 1e-4 relative of the reference's (the per-op 1e-4 bar compounds over the layers)."""
+streams"); logits within 2e-3 + 1e-4 relative of the reference's.  That logit bar is a stated DEVIATION from
+north_star's 1e-4 + 1e-5 |ref|, which is a per-call bar: logits sit behind every layer's GEMVs and attention calls, each
+inside its own bar, and the differences compound.  What this file holds exactly is what the engine's user sees -- the
+argmax at every position and the greedy streams; the per-call bar stays authoritative and is held in
+tests/test_gpu_attention.py (attention) and tests/test_gpu_linear.py (projections)."""
 import os
 
 import numpy as np

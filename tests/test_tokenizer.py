@@ -68,3 +68,32 @@ def test_random_texts_against_the_reference(tokenizer_path):
                 continue  # the reference's merge loop underflows on an empty list (tokenizer.hpp:111)
             assert tok.encode(text, bos, eos) == ol.ref_tokenizer_encode(ref, text, bos, eos), (seed, text)
     ol.REF.ref_tokenizer_destroy(ref)
+
+
+@pytest.mark.skipif(ol.REF is None or not hasattr(ol.REF, "ref_tokenizer_create"), reason="oracle/_ref not built here")
+def test_tied_scores_and_floor_scores_against_the_reference(tmp_path):
+    """The merge order where it is decided by POSITION: a vocabulary whose merged pieces all share two scores (so most
+    rounds are ties, resolved to the leftmost pair, tokenizer.hpp:116 compares with >), overlapping candidates
+    ("aa" in "aaaa..."), and pieces scored at / below the -1e10 floor, which the reference never merges."""
+    import struct
+    singles = [bytes([c]) for c in b" ab"]
+    merged = [b"aa", b"ab", b"ba", b"bb", b" a", b"a ", b"aaa", b"aba", b"bab", b"aab", b"abab", b"aaaa", b" b", b"b "]
+    pieces = [b"<unk>", b"<s>", b"</s>"] + singles + merged + [b"bbb", b"  "]
+    scores = [0.0] * (3 + len(singles)) + [(-1.0 if i % 3 else -2.0) for i in range(len(merged))] + [-1e10, -3e10]
+    path = str(tmp_path / "ties.bin")
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("i", max(len(p) for p in pieces)))
+        for piece, score in zip(pieces, scores):
+            fh.write(struct.pack("fi", score, len(piece)))
+            fh.write(piece)
+    tok = nv.Tokenizer(path, len(pieces))
+    ref = ol.REF.ref_tokenizer_create(path.encode(), len(pieces))
+    assert ref
+    for seed in range(300):
+        n = 1 + int(splitmix64(7000 + seed, np.array([0], np.uint64))[0] % 48)
+        draws = splitmix64(8000 + seed, np.arange(n, dtype=np.uint64))
+        text = bytes(b" aabb"[int(d % 5)] for d in draws)
+        assert tok.encode(text, True, False) == ol.ref_tokenizer_encode(ref, text, True, False), (seed, text)
+    for text in (b"a" * 33, b"ab" * 20, b"b" * 9, b"  " * 5, b"abba" * 7):
+        assert tok.encode(text, True, True) == ol.ref_tokenizer_encode(ref, text, True, True), text
+    ol.REF.ref_tokenizer_destroy(ref)
