@@ -181,6 +181,8 @@ int nvk_batch_create(nvk_pool *pool, nvk_block_manager *bm, int max_seqs, int ma
         e = hipEventCreateWithFlags(&b->staged, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipMemset(b->d_tables, 0, tab);
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize(); // (the fill may still be in flight, and the batch's streams do not wait for the null stream)
     if (e != hipSuccess) {
         const int code = nvk::fail(e == hipErrorOutOfMemory ? NVK_ERR_OOM : NVK_ERR_HIP, "nvk_batch_create: %s",
                                    hipGetErrorString(e));

@@ -231,7 +231,10 @@ int ensure_workspace(nvk_pool *pool, size_t o_floats, size_t ml_floats, size_t a
         pool->arrivals = nullptr, pool->arrivals_cap = 0;
         const size_t want = std::max(arrival_ints, (size_t)4096);
         HIP_TRY(hipMalloc(&pool->arrivals, want * sizeof(int)));
+        // (hipMemset on the null stream may return before the fill has run, and the pool's stream is non-blocking:
+        // it does not wait for the null stream.  The first launch must find zeros: fill, then wait for the device.)
         HIP_TRY(hipMemset(pool->arrivals, 0, want * sizeof(int)));
+        HIP_TRY(hipDeviceSynchronize());
         pool->arrivals_cap = want;
         pool->ws_generation++;
     }
