@@ -223,8 +223,9 @@ def extra_workloads(nv, torch, dev, args):
     of EXTRA_STEPS layer-calls each: the median region is the number, the fastest is beside it (box-to-box and
     region-to-region spread is 1-4 % on these)."""
     res = {}
-    for name in ("config3", "config4", "5a", "5b"):
-        work = make_workload(name)
+    for name in ("config3", "config4", "5a", "5b", "config2_head_shard_rank"):
+        # (the last one: what each GPU of an 8-way head-sharded config 2 runs -- 4 q-heads / 1 kv-head of every sequence)
+        work = make_workload("config2", 0, "shard8") if name == "config2_head_shard_rank" else make_workload(name)
         g = work.geom
         uniform_batch = bool((work.ctx_lens == work.ctx_lens[0]).all())
         flags = nv.AUTO | (nv.UNIFORM if uniform_batch else 0)
@@ -262,6 +263,10 @@ def extra_workloads(nv, torch, dev, args):
                 reused = {"replan_every": 32, "steps": 32, "regions": EXTRA_REGIONS, "ms_per_step": round(r_ms, 4),
                           "ms_per_step_min": round(min(rr), 4),
                           "GBps": round(nbytes / (r_ms * 1e-3) / 1e9, 1), "frac": frac(r_ms)}
+            # the same launches as a model step would replay them: one plan, 32 layer-calls in ONE hipGraph
+            g_ms = nv.decode_bench_graph(pool, 0, work.num_seqs, g.n_heads, q, tabs, work.max_blocks, ctx, work.max_ctx,
+                                         out, flags, 0, layers_per_graph=32, warmup=2, iters=5)
+            graph = {"layers_per_graph": 32, "launches": 5, "ms_per_step": round(g_ms, 4), "frac": frac(g_ms)}
             traffic, traffic_source = profiled_traffic(work.name, kname)
             res[name] = {"workload": work.name, "steps": EXTRA_STEPS, "regions": EXTRA_REGIONS,
                          "ms_per_step": round(step_ms, 4), "ms_per_step_min": round(step_min, 4),
@@ -271,7 +276,8 @@ def extra_workloads(nv, torch, dev, args):
                          "kernel_frac": frac(attn_ms),
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": nbytes,
                          "plan": "none: uniform lengths" if uniform_batch else "nvk_plan_kernel every layer-call",
-                         "tokens_per_s": round(work.num_seqs / (step_ms * 1e-3), 1), "checked": checked}
+                         "tokens_per_s": round(work.num_seqs / (step_ms * 1e-3), 1), "checked": checked,
+                         "graph_replay_of_32_layer_calls": graph}
             if reused is not None:
                 res[name]["plan_reused_over_32_layer_calls"] = reused
         del q, tabs, ctx, out
@@ -740,31 +746,39 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
         pool.fill_uniform(0, 1 + 16 * rank, 2 + 16 * rank)
         q, tabs, ctx, out = device_inputs(work)
         torch.cuda.synchronize()
-        wall, step_ms, attn_ms = head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, 0, steps, 3,
-                                                  args.backend, rank, world, local_rank, dev, barrier)
-        wall, step_ms, attn_ms = reduce_max(wall, step_ms, attn_ms)
-        checked = self_check(work, out.cpu().numpy(), 1 + 16 * rank, 2 + 16 * rank, check_picks(work))  # this rank's heads
-        ms = wall * 1e3 / steps
-        nbytes = work.algorithmic_bytes()  # this rank's heads of the whole batch
-        shard_bytes = work.num_seqs * g.n_heads * g.head_dim * 4
-        res["5b_head_sharded"] = {
-            "workload": f"{full.name}: ONE batch, {g.n_kv_heads} of {gf.n_kv_heads} kv-heads per GPU x {world} GPUs",
-            "scaling": "weak in bytes per GPU (the batch grows with the GPUs, the heads per GPU shrink)",
-            "collective": ("ncclAllGather (RCCL) through nvk_shard_*, on its own stream under the next layer-call"
-                           if args.backend == "nccl" else "gloo on host copies: rehearsal"),
-            "gather_bytes_per_rank": {"sent": shard_bytes, "gathered": shard_bytes * world},
-            "steps": steps, "ms_per_step": round(ms, 4), "event_ms_per_step": round(step_ms, 4),
-            "GBps": round(nbytes * world / (ms * 1e-3) / 1e9, 1),
-            "frac_per_gpu": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "slowest_kernel_ms": round(attn_ms, 4), "sequences": work.num_seqs,
-            "tokens_per_s": round(work.num_seqs / (ms * 1e-3), 1), "checked_on_rank0": checked}
-        publish()
+        # both places the collective can run (nvk_shard_set_gather_mode): hidden on the shard's own stream under the
+        # next layer-call (the default with more than one rank), and in line behind the attention on the compute stream
+        for key, mode in (("5b_head_sharded", "overlapped"), ("5b_head_sharded_inline", "inline")):
+            if mode == "inline" and args.backend != "nccl":
+                continue  # (the gloo rehearsal has one form only)
+            info = {}
+            wall, step_ms, attn_ms = head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, 0, steps, 3,
+                                                      args.backend, rank, world, local_rank, dev, barrier, mode, info)
+            wall, step_ms, attn_ms = reduce_max(wall, step_ms, attn_ms)
+            checked = self_check(work, out.cpu().numpy(), 1 + 16 * rank, 2 + 16 * rank, check_picks(work))  # this rank's heads
+            ms = wall * 1e3 / steps
+            nbytes = work.algorithmic_bytes()  # this rank's heads of the whole batch
+            shard_bytes = work.num_seqs * g.n_heads * g.head_dim * 4
+            res[key] = {
+                "workload": f"{full.name}: ONE batch, {g.n_kv_heads} of {gf.n_kv_heads} kv-heads per GPU x {world} GPUs",
+                "scaling": "weak in bytes per GPU (the batch grows with the GPUs, the heads per GPU shrink)",
+                "collective": (f"ncclAllGather (RCCL) through nvk_shard_*, {info.get('gather_mode')}: "
+                               + ("on its own stream under the next layer-call" if info.get("gather_mode") == "overlapped"
+                                  else "on the compute stream behind the attention")
+                               if args.backend == "nccl" else "gloo on host copies: rehearsal"),
+                "gather_bytes_per_rank": {"sent": shard_bytes, "gathered": shard_bytes * world},
+                "steps": steps, "ms_per_step": round(ms, 4), "event_ms_per_step": round(step_ms, 4),
+                "GBps": round(nbytes * world / (ms * 1e-3) / 1e9, 1),
+                "frac_per_gpu": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "slowest_kernel_ms": round(attn_ms, 4), "sequences": work.num_seqs,
+                "tokens_per_s": round(work.num_seqs / (ms * 1e-3), 1), "checked_on_rank0": checked}
+            publish()
         del q, tabs, ctx, out
     torch.cuda.empty_cache()
 
 
 def head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, chunk, steps, warmup, backend, rank, world,
-                     local_rank, dev, barrier):
+                     local_rank, dev, barrier, gather_mode="auto", info=None):
     """K x (attention of this rank's heads, then ONE all-gather of out): (wall s, event ms per step, kernel ms).
 
     With RCCL the gather goes through the library's own C ABI (nvk_shard_*: ncclAllGather called directly, on a
@@ -780,8 +794,10 @@ def head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, 
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
     assert stream != 0  # (the C ABI reads a NULL stream as "the pool's own stream")
-    outs = [out, torch.empty_like(out)]
     gath = [torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev) for _ in range(2)]
+    # with RCCL the attention writes its slice where the gather wants it, gathered[b][rank] (an IN-PLACE all-gather:
+    # no copy of the rank's own rows; with one rank nothing moves at all); the gloo rehearsal keeps separate buffers
+    outs = [gath[0][rank], gath[1][rank]] if backend == "nccl" else [out, torch.empty_like(out)]
     shard = None
     try:
         if backend == "nccl":
@@ -789,6 +805,10 @@ def head_sharded_leg(nv, torch, dist, hs, pool, work, q, tabs, ctx, out, flags, 
             if world > 1:
                 dist.broadcast_object_list(ids, src=0)
             shard = sh.NvkShard(rank, world, ids[0], local_rank, hs.n_heads, hs.n_kv_heads)
+            if gather_mode != "auto":
+                shard.set_gather_mode({"overlapped": shard.GATHER_OVERLAPPED, "inline": shard.GATHER_INLINE}[gather_mode])
+            if info is not None:
+                info["gather_mode"] = shard.gather_mode
 
         def step(i):
             b = i % 2
@@ -843,6 +863,9 @@ def main():
     ap.add_argument("--shard", default="seq", choices=["seq", "heads"],
                     help="seq: a private batch per GPU, no collective (default); heads: kv-head groups per GPU, "
                          "one RCCL all-gather of out per layer-call")
+    ap.add_argument("--gather", default="auto", choices=["auto", "overlapped", "inline"],
+                    help="--shard heads: where the all-gather runs (nvk_shard_set_gather_mode): the shard's own stream, hidden "
+                         "under the next layer-call, or the compute stream; auto = overlapped with more than one rank")
     ap.add_argument("--mode", default="auto", choices=["auto", "single", "split"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--replan", type=int, default=1,
@@ -974,9 +997,10 @@ def main():
             rotated = (r_step, r_attn)
         torch.cuda.synchronize()
     else:
+        shard_info = {}
         wall, step_ms, attn_ms = head_sharded_leg(nv, torch, dist if world > 1 else None, hs, pool, work, q, tabs, ctx, out,
                                                   flags, args.chunk, args.steps, args.warmup, args.backend, rank, world,
-                                                  local_rank, dev, barrier)
+                                                  local_rank, dev, barrier, args.gather, shard_info)
         out_host = out.cpu().numpy()
 
     if world > 1:
@@ -1016,7 +1040,7 @@ def main():
                        "merge": args.merge, "prewarm_ms": args.prewarm_ms,
                        "parallelism": (f"sequence-sharded x{world}, no collective" if args.shard == "seq" else
                                        f"head-sharded x{world}, one all-gather of out per layer-call ("
-                                       + ("RCCL via nvk_shard_*, overlapped with the next layer-call" if args.backend == "nccl"
+                                       + (f"RCCL via nvk_shard_*, {shard_info.get('gather_mode')}" if args.backend == "nccl"
                                           else "gloo on host copies: rehearsal") + ")")},
             "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
             "tokens_per_s": round(seqs_all / (ms_per_step * 1e-3), 1),

@@ -325,6 +325,14 @@ int nvk_decode_bench_layers(nvk_pool *pool, int first_layer, int n_rotate, int n
                             const float *q_dev, const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev,
                             int max_ctx, float *out_dev, int flags, int chunk_tokens, int replan_every, int warmup,
                             int iters, float *total_ms, float *attn_ms);
+/* The same layer-calls as a model step would issue them under hipGraph replay: the plan is built once, then
+ * layers_per_graph layer-calls (call i reading layer first_layer + i % n_rotate) are captured from the pool's stream
+ * into ONE graph, which is launched `warmup` times untimed and `iters` times between a pair of HIP events.
+ * total_ms = region / (iters x layers_per_graph): the STEP of a layer-call inside a replayed model step. */
+int nvk_decode_bench_graph(nvk_pool *pool, int first_layer, int n_rotate, int num_seqs, int n_heads, const float *q_dev,
+                           const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
+                           float *out_dev, int flags, int chunk_tokens, int layers_per_graph, int warmup, int iters,
+                           float *total_ms);
 /* Name of the attention kernel instantiation a launch of this shape runs (as rocprofv3 prints it), for matching
  * profiles to launches. */
 int nvk_decode_kernel_name(nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int flags, int chunk_tokens,
@@ -388,8 +396,20 @@ int nvk_bind_pool(nvk_pool *pool, int layer);
  *       shard's communication stream behind an event: it runs under whatever `compute_stream` does next (the next
  *       layer-call's attention).  `buffer` (0 or 1) names which of two (out_local, gathered) buffer pairs the call
  *       uses; a pair is reused only after its gather has finished (the call orders that itself).
+ *       IN PLACE: out_local_dev may be the rank's own slot of the result, gathered_dev + rank * (num_seqs x H/G x
+ *       head_dim) floats (ncclAllGather's in-place form): the attention then writes its rows where the gather wants
+ *       them and no copy of the rank's own rows is made -- with one rank nothing moves at all.
  *   nvk_shard_wait_gather     makes `stream` (NULL: the calling thread) wait until buffer's gather has landed --
- *       before the consumer of `gathered` (the wo projection, include/core/model.hpp:224) reads it. */
+ *       before the consumer of `gathered` (the wo projection, include/core/model.hpp:224) reads it.
+ *   nvk_shard_set_gather_mode where nvk_shard_decode_gather runs the collective.  OVERLAPPED: on the shard's own
+ *       stream, as described above (the hand-over costs the compute stream 8-9 us per layer-call: worth it wherever
+ *       a real collective is hidden).  INLINE: on the compute stream right behind the attention (no hand-over,
+ *       nothing hidden).  AUTO (default): OVERLAPPED with more than one rank, INLINE with one, where the "gather" is
+ *       a device copy.  Same protocol for the caller either way (buffers, nvk_shard_wait_gather).
+ *       nvk_shard_gather_mode says which of the two a call would use now. */
+#define NVK_SHARD_GATHER_AUTO 0
+#define NVK_SHARD_GATHER_OVERLAPPED 1
+#define NVK_SHARD_GATHER_INLINE 2
 typedef struct nvk_shard nvk_shard;
 int       nvk_shard_head_range(int rank, int world, int n_heads, int n_kv_heads, int *out4);
 long long nvk_shard_gather_bytes(int num_seqs, int n_heads, int head_dim, int world);
@@ -405,6 +425,8 @@ int       nvk_shard_decode_gather(nvk_shard *shard, nvk_pool *pool, int layer, i
                                   float *out_local_dev, float *gathered_dev, int buffer, int flags, int chunk_tokens,
                                   void *compute_stream);
 int       nvk_shard_wait_gather(nvk_shard *shard, int buffer, void *stream);
+int       nvk_shard_set_gather_mode(nvk_shard *shard, int mode);
+int       nvk_shard_gather_mode(const nvk_shard *shard);
 
 /* ------------------------------------------------------------ decode batch --
  * Per-request block tables kept on the device, and one append + attention call

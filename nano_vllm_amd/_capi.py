@@ -115,6 +115,11 @@ SIGNATURES = {
         [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
          C.c_int, _f, _f],
     ),
+    "nvk_decode_bench_graph": (
+        C.c_int,
+        [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.c_int, _f],
+    ),
     "nvk_decode_kernel_name": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "nvk_shard_head_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _i]),
     "nvk_shard_gather_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -126,6 +131,8 @@ SIGNATURES = {
     "nvk_shard_decode_gather": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int,
                                           C.c_int, C.c_int, _vp]),
     "nvk_shard_wait_gather": (C.c_int, [_vp, C.c_int, _vp]),
+    "nvk_shard_set_gather_mode": (C.c_int, [_vp, C.c_int]),
+    "nvk_shard_gather_mode": (C.c_int, [_vp]),
     "nvk_plan_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "nvk_plan_destroy": (C.c_int, [_vp]),
     "nvk_plan_build": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -193,6 +193,20 @@ def decode_bench(pool: PagedKVPool, layer: int, num_seqs: int, n_heads: int, q_d
     return float(total.value), (float(attn.value) if want_attn else None)
 
 
+def decode_bench_graph(pool: PagedKVPool, layer: int, num_seqs: int, n_heads: int, q_dev, block_tables_dev,
+                       max_blocks: int, ctx_lens_dev, max_ctx: int, out_dev, flags: int = AUTO, chunk_tokens: int = 0,
+                       layers_per_graph: int = 32, warmup: int = 2, iters: int = 5, rotate_layers: int = 1) -> float:
+    """ms per layer-call when ``layers_per_graph`` layer-calls (one plan, as for the layers of a model step) are
+    captured into ONE hipGraph and replayed ``iters`` times on the pool's stream."""
+    total = C.c_float(0.0)
+    _capi.check(_capi.lib.nvk_decode_bench_graph(pool.handle, int(layer), int(rotate_layers), int(num_seqs),
+                                                 int(n_heads), _devptr(q_dev), _devptr(block_tables_dev),
+                                                 int(max_blocks), _devptr(ctx_lens_dev), int(max_ctx),
+                                                 _devptr(out_dev), int(flags), int(chunk_tokens),
+                                                 int(layers_per_graph), int(warmup), int(iters), C.byref(total)))
+    return float(total.value)
+
+
 def decode_kernel_name(pool: PagedKVPool, num_seqs: int, n_heads: int, max_ctx: int, flags: int = AUTO,
                        chunk_tokens: int = 0) -> str:
     """The attention kernel instantiation a launch of this shape runs, as rocprofv3 names it."""

@@ -2053,6 +2053,76 @@ int nvk_decode_bench_layers(nvk_pool *pool, int first_layer, int n_rotate, int n
     return NVK_OK;
 }
 
+// A model step's worth of layer-calls as ONE hipGraph: the plan is built once (outside the graph, as nvk_plan_build
+// per model step), `layers_per_graph` layer-calls are recorded from the pool's stream into a graph, and the graph is
+// replayed.  What the replay removes is the host's share of every launch; the device-side hand-over from one
+// layer-call's kernel to the next stays.  total_ms = region / (iters x layers_per_graph).
+int nvk_decode_bench_graph(nvk_pool *pool, int first_layer, int n_rotate, int num_seqs, int n_heads, const float *q_dev,
+                           const int *block_tables_dev, int max_blocks, const int *ctx_lens_dev, int max_ctx,
+                           float *out_dev, int flags, int chunk_tokens, int layers_per_graph, int warmup, int iters,
+                           float *total_ms)
+{
+    int rc = check_pool_layer(pool, first_layer, "nvk_decode_bench_graph");
+    if (rc != NVK_OK)
+        return rc;
+    if (n_rotate < 1 || first_layer + n_rotate > pool->n_layers)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_bench_graph: layers [%d, %d) outside the pool's %d", first_layer,
+                         first_layer + n_rotate, pool->n_layers);
+    if (iters < 1 || warmup < 0 || num_seqs <= 0 || iters > 100000 || layers_per_graph < 1 || layers_per_graph > 1024
+        || !total_ms)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_decode_bench_graph: bad arguments");
+    NVK_SCOPE(pool->device);
+    hipStream_t st   = pool->stream;
+    nvk_plan   *plan = nullptr;
+    rc               = own_plan_of(pool, &plan);
+    if (rc != NVK_OK)
+        return rc;
+    // the plan and one direct layer-call first: every buffer is sized before the capture starts
+    rc = build_plan(plan, num_seqs, n_heads, ctx_lens_dev, max_ctx, flags, chunk_tokens, st);
+    if (rc == NVK_OK)
+        rc = enqueue_planned(pool, first_layer, plan, q_dev, block_tables_dev, max_blocks, out_dev, st, nullptr, nullptr);
+    if (rc != NVK_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    hipGraph_t     graph = nullptr;
+    hipGraphExec_t exec  = nullptr;
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < layers_per_graph && rc == NVK_OK; i++)
+        rc = enqueue_planned(pool, first_layer + i % n_rotate, plan, q_dev, block_tables_dev, max_blocks, out_dev, st,
+                             nullptr, nullptr);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != NVK_OK) {
+        if (graph)
+            (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e == hipSuccess)
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    for (int i = 0; i < warmup && e == hipSuccess; i++)
+        e = hipGraphLaunch(exec, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e == hipSuccess)
+        e = hipEventRecord(pool->ev_a, st);
+    for (int i = 0; i < iters && e == hipSuccess; i++)
+        e = hipGraphLaunch(exec, st);
+    if (e == hipSuccess)
+        e = hipEventRecord(pool->ev_b, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    float whole = 0.f;
+    if (e == hipSuccess)
+        e = hipEventElapsedTime(&whole, pool->ev_a, pool->ev_b);
+    if (exec)
+        (void)hipGraphExecDestroy(exec);
+    if (graph)
+        (void)hipGraphDestroy(graph);
+    if (e != hipSuccess)
+        return nvk::fail(NVK_ERR_HIP, "nvk_decode_bench_graph: %s", hipGetErrorString(e));
+    *total_ms = whole / ((float)iters * (float)layers_per_graph);
+    return NVK_OK;
+}
+
 int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_heads, float *q, const float *k_rows,
                                 const float *v_rows, const int *block_tables, int max_blocks, const int *chunk_starts,
                                 const int *chunk_lens, float rope_theta, int ptr_kind, void *stream)

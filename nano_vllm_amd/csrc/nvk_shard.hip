@@ -97,7 +97,25 @@ struct nvk_shard
     hipEvent_t  computed[2] = {nullptr, nullptr}; // out buffer b holds this layer-call's slice
     hipEvent_t  gathered[2] = {nullptr, nullptr}; // gathered buffer b is complete (and out buffer b free again)
     bool        pending[2]  = {false, false};
+    hipStream_t waited_on[2] = {nullptr, nullptr}; // the stream that has already been made to wait for gathered[b]
+    int         mode = NVK_SHARD_GATHER_AUTO;
 };
+
+namespace {
+
+// Where the collective of a layer-call runs.  Handing a layer-call's rows to a second stream and taking the gathered
+// rows back costs the compute stream 8-9 us per layer-call on this runtime even when nothing has to wait (a record
+// and a wait packet in its queue; tools/shard_sync_probe.hip, profiles/r03_shard_sync_probe.log: 27.7 us per step
+// plain, 36.8 handed over, 29.3 with the copy in line), so it pays only where there is a collective to hide: with
+// one rank the "gather" is a device copy, and it goes in line.
+bool gather_overlapped(const nvk_shard *s)
+{
+    if (s->mode == NVK_SHARD_GATHER_AUTO)
+        return s->world > 1;
+    return s->mode == NVK_SHARD_GATHER_OVERLAPPED;
+}
+
+} // namespace
 
 extern "C" {
 
@@ -257,20 +275,34 @@ int nvk_shard_decode_gather(nvk_shard *s, nvk_pool *pool, int layer, int num_seq
     if (rc != NVK_OK)
         return rc;
     hipStream_t cs = compute_stream ? (hipStream_t)compute_stream : (hipStream_t)pool_stream;
-    // out buffer `buffer` is free again once the gather that last read it has finished
-    if (s->pending[buffer])
+    const bool  overlapped = gather_overlapped(s);
+    // out buffer `buffer` is free again once the gather that last read it has finished (nothing to wait for when
+    // this stream has already been made to wait for that gather -- its consumer ran here -- or, inline, when the
+    // gather itself ran on this stream)
+    if (s->pending[buffer] && s->waited_on[buffer] != cs)
         HIP_TRY_S(hipStreamWaitEvent(cs, s->gathered[buffer], 0));
     rc = nvk_decode_device(pool, layer, num_seqs, s->n_heads / s->world, q_local_dev, block_tables_dev, max_blocks,
                            ctx_lens_dev, max_ctx, out_local_dev, flags, chunk_tokens, (void *)cs);
     if (rc != NVK_OK)
         return rc;
+    if (!overlapped) {
+        // the collective right behind the attention on the compute stream: no hand-over, nothing hidden either
+        rc = nvk_shard_all_gather_out(s, out_local_dev, gathered_dev, num_seqs, geo[4], (void *)cs);
+        if (rc != NVK_OK)
+            return rc;
+        HIP_TRY_S(hipEventRecord(s->gathered[buffer], cs)); // (for waiters on other streams and for the host)
+        s->pending[buffer]   = true;
+        s->waited_on[buffer] = cs; // stream order does it
+        return NVK_OK;
+    }
     HIP_TRY_S(hipEventRecord(s->computed[buffer], cs));
     HIP_TRY_S(hipStreamWaitEvent(s->comm_stream, s->computed[buffer], 0));
     rc = nvk_shard_all_gather_out(s, out_local_dev, gathered_dev, num_seqs, geo[4], (void *)s->comm_stream);
     if (rc != NVK_OK)
         return rc;
     HIP_TRY_S(hipEventRecord(s->gathered[buffer], s->comm_stream));
-    s->pending[buffer] = true;
+    s->pending[buffer]   = true;
+    s->waited_on[buffer] = nullptr;
     return NVK_OK;
 }
 
@@ -281,11 +313,30 @@ int nvk_shard_wait_gather(nvk_shard *s, int buffer, void *stream)
     if (!s->pending[buffer])
         return NVK_OK;
     NVK_SCOPE(s->device);
-    if (stream)
-        HIP_TRY_S(hipStreamWaitEvent((hipStream_t)stream, s->gathered[buffer], 0));
+    if (stream) {
+        if (s->waited_on[buffer] != (hipStream_t)stream) { // (a stream waits for a gather once)
+            HIP_TRY_S(hipStreamWaitEvent((hipStream_t)stream, s->gathered[buffer], 0));
+            s->waited_on[buffer] = (hipStream_t)stream;
+        }
+    }
     else
         HIP_TRY_S(hipEventSynchronize(s->gathered[buffer]));
     return NVK_OK;
+}
+
+int nvk_shard_set_gather_mode(nvk_shard *s, int mode)
+{
+    if (!s || (mode != NVK_SHARD_GATHER_AUTO && mode != NVK_SHARD_GATHER_OVERLAPPED && mode != NVK_SHARD_GATHER_INLINE))
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_shard_set_gather_mode: bad arguments");
+    s->mode = mode;
+    return NVK_OK;
+}
+
+int nvk_shard_gather_mode(const nvk_shard *s)
+{
+    if (!s)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_shard_gather_mode: null shard");
+    return gather_overlapped(s) ? NVK_SHARD_GATHER_OVERLAPPED : NVK_SHARD_GATHER_INLINE;
 }
 
 } // extern "C"

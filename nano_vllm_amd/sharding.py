@@ -217,6 +217,17 @@ class NvkShard:
 
         self._capi.check(self._capi.lib.nvk_shard_wait_gather(self._h, int(buffer), _devptr(stream)))
 
+    GATHER_AUTO, GATHER_OVERLAPPED, GATHER_INLINE = 0, 1, 2
+
+    def set_gather_mode(self, mode: int) -> None:
+        """Where decode_gather runs the collective: its own stream (hidden under the next layer-call; the hand-over
+        costs the compute stream 8-9 us), or in line on the compute stream; AUTO = overlapped iff world > 1."""
+        self._capi.check(self._capi.lib.nvk_shard_set_gather_mode(self._h, int(mode)))
+
+    @property
+    def gather_mode(self) -> str:
+        return {1: "overlapped", 2: "inline"}[self._capi.check(self._capi.lib.nvk_shard_gather_mode(self._h))]
+
 
 def assemble_heads(gathered):
     """[G, num_seqs, n_heads/G, head_dim] -> [num_seqs, n_heads, head_dim] (the reference's ``out`` layout).

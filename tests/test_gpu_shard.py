@@ -15,7 +15,10 @@ from nano_vllm_amd import workloads as wl
 pytestmark = pytest.mark.gpu
 
 
-def test_one_rank_communicator_gathers_what_decode_device_writes():
+@pytest.mark.parametrize("mode", ["auto", "overlapped", "inline"])
+def test_one_rank_communicator_gathers_what_decode_device_writes(mode):
+    """Both places the collective can run (nvk_shard_set_gather_mode): on the shard's own stream behind an event
+    (what more than one rank gets), or in line on the compute stream (what one rank gets by default)."""
     g = wl.Geometry(32, 8, 128, 16)
     ctx = np.array([700, 33, 2048, 1, 513, 0, 640], np.int32)
     work = wl.fragmented_workload("shard1", ctx, g)
@@ -26,6 +29,10 @@ def test_one_rank_communicator_gathers_what_decode_device_writes():
         shard = sh.NvkShard(0, 1, sh.NvkShard.new_unique_id(), 0, g.n_heads, g.n_kv_heads)
         assert shard.info() == {"rank": 0, "world": 1, "local_heads": 32, "local_kv_heads": 8, "first_head": 0,
                                 "first_kv_head": 0}
+        assert shard.gather_mode == "inline"  # AUTO with one rank
+        if mode != "auto":
+            shard.set_gather_mode({"overlapped": shard.GATHER_OVERLAPPED, "inline": shard.GATHER_INLINE}[mode])
+            assert shard.gather_mode == mode
         q = work.q()
         n = work.num_seqs
         qd, td, cd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(ctx)
@@ -39,6 +46,8 @@ def test_one_rank_communicator_gathers_what_decode_device_writes():
             shard.decode_gather(pool, layer, n, qd, td, work.max_blocks, cd, work.max_ctx, outs[b], gath[b], b,
                                 compute_stream=st)
             if layer > 0:  # the consumer of the previous layer-call's gathered rows
+                shard.wait_gather((layer - 1) % 2, st)  # (on the stream: a second wait for the same gather is skipped)
+                shard.wait_gather((layer - 1) % 2, st)
                 shard.wait_gather((layer - 1) % 2)
                 got.append(gath[(layer - 1) % 2].numpy().copy())
         shard.wait_gather((L - 1) % 2)
@@ -66,4 +75,25 @@ def test_shard_rejects_a_pool_of_the_wrong_width():
             shard.decode_gather(pool, 0, 1, z, z, 1, z, 1, z, z, 0)
         with pytest.raises(nv.NvkError):
             shard.decode_gather(pool, 0, 1, z, z, 1, z, 1, z, z, 2)  # buffer must be 0 or 1
+        shard.close()
+
+
+def test_in_place_gather_writes_the_ranks_own_slot_directly():
+    """out_local = gathered + rank * slice (ncclAllGather's in-place form): the attention writes its rows where the
+    gather wants them; with one rank the result is simply there."""
+    g = wl.Geometry(8, 2, 64, 16)
+    ctx = np.array([90, 300, 17], np.int32)
+    work = wl.fragmented_workload("shard_inplace", ctx, g, perm_seed=9)
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, 5, 6)
+        shard = sh.NvkShard(0, 1, sh.NvkShard.new_unique_id(), 0, g.n_heads, g.n_kv_heads)
+        q = work.q()
+        qd, td, cd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(ctx)
+        gath = DeviceArray(np.full((1,) + q.shape, np.nan, np.float32))
+        for mode in (shard.GATHER_INLINE, shard.GATHER_OVERLAPPED):
+            shard.set_gather_mode(mode)
+            shard.decode_gather(pool, 0, work.num_seqs, qd, td, work.max_blocks, cd, work.max_ctx, gath, gath, 0)
+            shard.wait_gather(0)
+            want = nv.decode(pool, 0, q, work.block_tables, ctx)
+            assert np.array_equal(gath.numpy()[0].view(np.uint32), want.view(np.uint32))
         shard.close()
