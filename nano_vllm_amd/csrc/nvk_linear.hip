@@ -68,6 +68,10 @@
 #ifndef NVK_SKINNY16_MAX_ROWS
 #define NVK_SKINNY16_MAX_ROWS 16 // up to here the weight-streaming kernel uses 16 x 16 MFMA tiles (0: always 32 x 32)
 #endif
+#ifndef NVK_SKINNY16_TM2
+#define NVK_SKINNY16_TM2 0 // 1: 17-32 rows on 16 x 16 tiles with both row tiles in one wave (weights cross L2 once).  Built and measured in
+                           // round 3: 32.3 us against 33.0 at 6144 columns -- the kernel is not bound by the second reading -- not kept
+#endif
 #ifndef NVK_SKINNY16_WIDE
 #define NVK_SKINNY16_WIDE 1 // 17-64 rows over few columns: 16 x 16 tiles, one workgroup per row tile (0: 32 x 32 tiles)
 #endif
@@ -370,8 +374,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // T = 32: 32 x 32 tiles on v_mfma_f32_32x32x2_f32.  T = 16 (at most 16 rows): 16 x 16 tiles on
 // v_mfma_f32_16x16x4_f32 -- half the MFMA cycles spent on padding rows, twice the workgroups, half the LDS.
-// TM > 1 (T = 32 only): one wave multiplies TM row tiles by the same weight tile, so up to 32 * TM rows still stream
-// the weights once; BK is then 32 so that the waves' private LDS regions fit.
+// TM > 1: one wave multiplies TM row tiles by the same weight tile, so up to T * TM rows still stream the weights
+// once; BK is then 32 so that the waves' private LDS regions fit (two workgroups per CU).  <16, 2, 32> is the form for
+// 17-32 rows: two 16-row tiles per weight tile instead of a second workgroup per row tile that re-reads the weights
+// through L2 or a 32-row tile padded to 32 columns; measured no faster (NVK_SKINNY16_TM2, profiles/r03_qkv_kernel_stats_tm2.csv): off.
 // Four consecutive columns (col % 4 == 0) of row `row` of the q | k | v product, segment si = 0 / 1 / 2: what
 // nvk_rope_append_kernel does with them -- q and k rotated in their pairs by the row's position (positional.hpp:13-39),
 // q to `q_out`, k and v to the slot of token `pos` in the row's sequence (model.hpp:190-207).
@@ -464,15 +470,16 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
 
     constexpr int NACC = T == 32 ? 16 : 4; // accumulator registers of one tile
     f32x16 acc32[TM];
-    f32x4  acc16;
+    f32x4  acc16[TM];
 #pragma unroll
-    for (int t = 0; t < TM; t++)
+    for (int t = 0; t < TM; t++) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
             acc32[t][r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-        acc16[r] = 0.f;
+        for (int r = 0; r < 4; r++)
+            acc16[t][r] = 0.f;
+    }
     // lane (j, part) of MFMA e supplies element 4 * part + e of the chunk (8 wide at T = 32, 16 wide at T = 16)
     const float *pa = sa + j * LDS + 4 * part, *pb = sb + j * LDS + 4 * part;
     auto         multiply = [&]() {
@@ -488,11 +495,14 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
                 }
             }
             else {
-                const float4 a0 = *reinterpret_cast<const float4 *>(pa + CH * c);
-                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc16, 0, 0, 0);
-                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc16, 0, 0, 0);
-                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc16, 0, 0, 0);
-                acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc16, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < TM; t++) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(pa + t * T * LDS + CH * c);
+                    acc16[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc16[t], 0, 0, 0);
+                    acc16[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc16[t], 0, 0, 0);
+                    acc16[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc16[t], 0, 0, 0);
+                    acc16[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc16[t], 0, 0, 0);
+                }
             }
         }
     };
@@ -559,7 +569,7 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     for (int t = 0; t < TM; t++)
 #pragma unroll
         for (int r = 0; r < NACC; r++)
-            sa[(t * NACC + r) * 64 + lane] = T == 32 ? acc32[t][r] : acc16[r & 3]; // own region: operand reads are behind us
+            sa[(t * NACC + r) * 64 + lane] = T == 32 ? acc32[t][r] : acc16[t][r & 3]; // own region: operand reads are behind us
     __syncthreads();
     if (T == 16 && (EPI != kSkinnyPlain || SCALE)) { // T = 16, TM = 1: thread (r, l4) owns row 4 * (l4 / 16) + r, columns (l4 % 16) .. + 3
         if (tid < 64) {
@@ -947,7 +957,7 @@ bool tile16(int batch, const int *n, int nseg, int cus)
 }
 
 // the weight-streaming kernel's tile (16 or 32) and row tiles per wave for `batch` rows
-void skinny_choice(int batch, const int *n, int nseg, int cus, int *t, int *tm)
+void skinny_choice(int batch, const int *n, int nseg, int cus, int *t, int *tm, bool epilogue = false)
 {
     *t = tile16(batch, n, nseg, cus) ? 16 : 32;
     long long tiles = 0;
@@ -956,6 +966,10 @@ void skinny_choice(int batch, const int *n, int nseg, int cus, int *t, int *tm)
     // (several row tiles per wave only when the column tiles alone occupy the chip: with few columns, separate
     //  workgroups per row tile are twice as many workgroups and faster -- 2560 columns x 64 rows: 15.9 us against 24.6)
     *tm = (*t == 32 && NVK_SKINNY_TM && batch > 32 && tiles >= 128) ? (batch + 31) / 32 : 1;
+    // 17-32 rows on 16 x 16 tiles: both row tiles in one wave wherever the column tiles alone occupy the chip
+    // (not under a fused epilogue: RoPE + append wants a workgroup per row tile)
+    if (*t == 16 && NVK_SKINNY16_TM2 && !epilogue && batch > 16 && batch <= 32 && tiles >= cus)
+        *tm = 2;
 }
 
 int launch_linear(const float *in, int batch, int in_dim, const float *const *w, float *const *out, const int *n,
@@ -984,7 +998,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     // fused epilogues beyond the GEMV: the norm link in the 16 x 16 tile kernel up to 16 rows; RoPE + append wherever the
     // weight-streaming kernel gives every row tile a workgroup of its own; SwiGLU only in the GEMV
     int sk_t = 32, sk_tm = 1;
-    skinny_choice(batch, n, nseg, cus, &sk_t, &sk_tm);
+    skinny_choice(batch, n, nseg, cus, &sk_t, &sk_tm, rope != nullptr || link != nullptr);
     if (!gemv && (glu || (link && !(batch <= NVK_SKINNY16_MAX_ROWS && NVK_SKINNY16_MAX_ROWS <= 16))
                   || (rope && !(skinny && sk_tm == 1))))
         return nvk::fail(NVK_ERR_INVALID_ARG, "%s: internal: no fused epilogue for %d rows", who, batch);
@@ -1104,7 +1118,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             HIP_TRY(hipGetLastError());
             return NVK_OK;
         }
-        const void  *fn  = t == 16 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 64>
+        const void  *fn  = t == 16 ? (tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 2, 32>
+                                              : (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 64>)
                            : tm == 1 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 1, 64>
                            : tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 2, 32>
                                      : (const void *)nvk::nvk_gemm_skinny_kernel<32, 3, 32>;
@@ -1112,7 +1127,9 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         if (rc_lds != NVK_OK)
             return rc_lds;
         const dim3 grid((unsigned)wgs);
-        if (t == 16)
+        if (t == 16 && tm == 2)
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 2, 32>), grid, block, lds, st, p);
+        else if (t == 16)
             hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 1, 64>), grid, block, lds, st, p);
         else if (tm == 1)
             hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<32, 1, 64>), grid, block, lds, st, p);
@@ -1221,7 +1238,7 @@ bool nvk::qkv_rope_append_ok(int rows, int dim, int q_dim, int kv_dim, int devic
         return true;
     const int n[3] = {q_dim, kv_dim, kv_dim};
     int       t = 32, tm = 1;
-    skinny_choice(rows, n, 3, cu_count_of(device), &t, &tm);
+    skinny_choice(rows, n, 3, cu_count_of(device), &t, &tm, true);
     return tm == 1;
 }
 
