@@ -19,8 +19,8 @@ all: lib cli oracle ref
 
 lib: $(LIB)
 
-$(LIB): $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_shard.hip $(CSRC)/nvk_kernels.hip.h $(CSRC)/nvk_addr.hip.h $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp $(CSRC)/nvk_internal.h $(CSRC)/nvk_device_scope.h include/nvk_paged_attn.h
-	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_shard.hip $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp -ldl
+$(LIB): $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_shard.hip $(CSRC)/nvk_kernels.hip.h $(CSRC)/nvk_addr.hip.h $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp $(CSRC)/nvk_model_group.cpp $(CSRC)/nvk_internal.h $(CSRC)/nvk_device_scope.h include/nvk_paged_attn.h
+	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/nvk_paged_attn.hip $(CSRC)/nvk_batch.hip $(CSRC)/nvk_linear.hip $(CSRC)/nvk_model.hip $(CSRC)/nvk_shard.hip $(CSRC)/nvk_block_manager.cpp $(CSRC)/nvk_tokenizer.cpp $(CSRC)/nvk_model_group.cpp -ldl -lpthread
 
 # the reference's command line over the library (tools/nvk_run.cpp): host-only C++ over the C ABI
 CLI := nano_vllm_amd/nvk_run

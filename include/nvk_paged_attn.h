@@ -544,6 +544,35 @@ int nvk_model_step(nvk_model *model, const int *request_ids, const int *tokens, 
 /* LlamaModel::forward(token, pos) for ONE sequence (request 0, added on first use); pos must be its length */
 int nvk_model_forward(nvk_model *model, int token, int pos, float *logits);
 
+/* ------------------------------------------- the model on several GPUs: sequence-sharded --
+ * SURVEY.md 8e, primary mode, at engine level: one nvk_model per entry of `devices` (its own copy of the weights, its
+ * own pool, allocator and batch), each driven by a host thread of its own.  A request is placed on ONE member when it
+ * is admitted -- the member whose running requests promise the fewest tokens, lowest index on ties -- and stays there:
+ * the members share nothing, no collective exists on the data path, and every request's token stream is exactly the one
+ * a single nvk_model produces for it.
+ * ref: what is split is the scheduler's running list, include/scheduler/scheduler.hpp:66-103, with
+ *      Request::block_ids (include/scheduler/request.hpp:74) private to each request; the attention itself touches one
+ *      sequence at a time (include/core/attention.hpp:82-159).  The reference has one process and one device.
+ * `devices` may name a device more than once (two members on one GPU: a rehearsal of two GPUs on a one-GPU box).
+ *   nvk_model_group_add_request   expected_tokens = what the request promises (prompt + max_tokens): the balance;
+ *                                 returns the member index (>= 0) or a negative status (NVK_ERR_OOM: every member full)
+ *   nvk_model_group_step_chunks   nvk_model_step_chunks for a list that may span members: each member runs its share
+ *                                 (in list order) on its own thread, all at once; results come back in list order. */
+typedef struct nvk_model_group nvk_model_group;
+int nvk_model_group_load(const char *checkpoint_path, int block_size, int num_blocks, int max_seqs_per_member,
+                         int n_members, const int *devices, nvk_model_group **out_group);
+int nvk_model_group_destroy(nvk_model_group *group);
+int nvk_model_group_size(const nvk_model_group *group);
+int nvk_model_group_config(const nvk_model_group *group, int *out8);
+int nvk_model_group_member_device(const nvk_model_group *group, int member);
+int nvk_model_group_member_of(const nvk_model_group *group, int request_id); /* -1: not running */
+int nvk_model_group_add_request(nvk_model_group *group, int request_id, int expected_tokens);
+int nvk_model_group_finish_request(nvk_model_group *group, int request_id);
+int nvk_model_group_request_len(const nvk_model_group *group, int request_id);
+int nvk_model_group_step_chunks(nvk_model_group *group, const int *request_ids, const int *chunk_lens, const int *tokens,
+                                int n, int *next_tokens, float *logits);
+int nvk_model_group_use_graphs(nvk_model_group *group, int on);
+
 /* ---------------------------------------------------------- BlockManager --
  * Host-side allocator returning the same ids in the same order as
  * ref: BlockManager, include/scheduler/block_manager.hpp:14-283

@@ -12,12 +12,12 @@ from .attention import AUTO, FREE_RUNNING, MERGE_IN_KERNEL, MERGE_SEPARATE, NO_P
 from .batch import DecodeBatch
 from .block_manager import BlockManager
 from .kv_pool import PagedKVPool
-from .model import LlamaModel
+from .model import LlamaModel, LlamaModelGroup
 from .tokenizer import Tokenizer
 from .linear import batch_add_rms_norm_device, batch_matmul2_device, batch_swiglu_ffn_device, batch_matmul_device, batch_rms_norm_device, qkv_project_device
 from .prefill import PREFILL_AUTO, PREFILL_ROWWISE, PREFILL_TILED, prefill, prefill_device, rope_append_chunks
 
 __all__ = [
-    "AUTO", "FREE_RUNNING", "MERGE_IN_KERNEL", "MERGE_SEPARATE", "NO_PAIRS", "NO_PLAN", "UNIFORM", "VECTOR_ONLY", "PREFILL_AUTO", "PREFILL_ROWWISE", "PREFILL_TILED", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "LlamaModel", "NvkError", "PagedKVPool", "Tokenizer", "batch_add_rms_norm_device", "batch_matmul2_device", "batch_matmul_device", "batch_swiglu_ffn_device", "batch_rms_norm_device", "bind_pool", "decode", "decode_kernel_name", "decode_device_noalloc", "noalloc_scratch_bytes",
+    "AUTO", "FREE_RUNNING", "MERGE_IN_KERNEL", "MERGE_SEPARATE", "NO_PAIRS", "NO_PLAN", "UNIFORM", "VECTOR_ONLY", "PREFILL_AUTO", "PREFILL_ROWWISE", "PREFILL_TILED", "SINGLE_PASS", "SPLIT_K", "BlockManager", "DecodeBatch", "DecodePlan", "LlamaModel", "LlamaModelGroup", "NvkError", "PagedKVPool", "Tokenizer", "batch_add_rms_norm_device", "batch_matmul2_device", "batch_matmul_device", "batch_swiglu_ffn_device", "batch_rms_norm_device", "bind_pool", "decode", "decode_kernel_name", "decode_device_noalloc", "noalloc_scratch_bytes",
     "decode_bench", "decode_bench_graph", "decode_device", "device_count", "host_cache_staged_bytes", "paged_attention", "prefill", "prefill_device", "qkv_project_device", "rope_append_chunks", "set_host_cache_policy", "standard_attention", "version",
 ]

@@ -133,6 +133,17 @@ SIGNATURES = {
     "nvk_shard_wait_gather": (C.c_int, [_vp, C.c_int, _vp]),
     "nvk_shard_set_gather_mode": (C.c_int, [_vp, C.c_int]),
     "nvk_shard_gather_mode": (C.c_int, [_vp]),
+    "nvk_model_group_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _i, C.POINTER(_vp)]),
+    "nvk_model_group_destroy": (C.c_int, [_vp]),
+    "nvk_model_group_size": (C.c_int, [_vp]),
+    "nvk_model_group_config": (C.c_int, [_vp, _i]),
+    "nvk_model_group_member_device": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_group_member_of": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_group_add_request": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "nvk_model_group_finish_request": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_group_request_len": (C.c_int, [_vp, C.c_int]),
+    "nvk_model_group_step_chunks": (C.c_int, [_vp, _i, _i, _i, C.c_int, _i, _f]),
+    "nvk_model_group_use_graphs": (C.c_int, [_vp, C.c_int]),
     "nvk_plan_create": (C.c_int, [_vp, C.POINTER(_vp)]),
     "nvk_plan_destroy": (C.c_int, [_vp]),
     "nvk_plan_build": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -92,3 +92,69 @@ class LlamaModel:
         _capi.check(_capi.lib.nvk_model_forward(self._h, int(token), int(pos),
                                                 logits.ctypes.data_as(C.POINTER(C.c_float))))
         return logits
+
+
+class LlamaModelGroup:
+    """The model sequence-sharded over several GPUs (``nvk_model_group_*``): one ``LlamaModel``'s worth of state per
+    entry of ``devices``, each driven by its own host thread inside the library; a request is placed on one member at
+    admission (fewest promised tokens first) and stays there, nothing is exchanged between members.  ``devices`` may
+    repeat a device (two members on one GPU: a rehearsal of two GPUs).  Same step interface as :class:`LlamaModel`."""
+
+    def __init__(self, path: str, devices: Sequence[int], block_size: int = 16, num_blocks: int = 256,
+                 max_seqs_per_member: int = 1):
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _capi.check(_capi.lib.nvk_model_group_load(os.fsencode(path), int(block_size), int(num_blocks),
+                                                   int(max_seqs_per_member), len(devices), devs, C.byref(h)))
+        self._h = h
+        cfg = (C.c_int * 8)()
+        _capi.check(_capi.lib.nvk_model_group_config(self._h, cfg))
+        (self.dim, self.hidden_dim, self.n_layers, self.n_heads, self.n_kv_heads, self.vocab_size, self.max_seq_len,
+         _) = (int(v) for v in cfg)
+        self.size = int(_capi.lib.nvk_model_group_size(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _capi.lib.nvk_model_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    __del__ = close
+
+    def add_request(self, request_id: int, expected_tokens: int) -> int:
+        """Places the request; returns the index of the member that took it."""
+        return _capi.check(_capi.lib.nvk_model_group_add_request(self._h, int(request_id), int(expected_tokens)))
+
+    def member_of(self, request_id: int) -> int:
+        return int(_capi.lib.nvk_model_group_member_of(self._h, int(request_id)))
+
+    def finish_request(self, request_id: int) -> None:
+        _capi.check(_capi.lib.nvk_model_group_finish_request(self._h, int(request_id)))
+
+    def request_len(self, request_id: int) -> int:
+        return _capi.check(_capi.lib.nvk_model_group_request_len(self._h, int(request_id)))
+
+    def use_graphs(self, on: bool) -> None:
+        _capi.check(_capi.lib.nvk_model_group_use_graphs(self._h, int(bool(on))))
+
+    def step_chunks(self, request_ids: Sequence[int], chunks: Sequence[Sequence[int]],
+                    want_logits: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        n = len(request_ids)
+        ids = (C.c_int * max(n, 1))(*[int(r) for r in request_ids])
+        lens = (C.c_int * max(n, 1))(*[len(c) for c in chunks])
+        flat = [int(t) for c in chunks for t in c]
+        toks = (C.c_int * max(len(flat), 1))(*flat)
+        nxt = (C.c_int * max(n, 1))()
+        logits = np.empty((n, self.vocab_size), np.float32) if want_logits else None
+        _capi.check(_capi.lib.nvk_model_group_step_chunks(
+            self._h, ids, lens, toks, n, nxt,
+            logits.ctypes.data_as(C.POINTER(C.c_float)) if logits is not None else None))
+        return np.array(nxt[:n], np.int32), logits
+
+    def step(self, request_ids: Sequence[int], tokens: Sequence[int], want_logits: bool = False):
+        return self.step_chunks(request_ids, [[int(t)] for t in tokens], want_logits)

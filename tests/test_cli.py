@@ -96,9 +96,13 @@ def test_input_json_batched(model_dir, tmp_path):
     path.write_text(json.dumps({"name": "test", "requests": reqs}))
     want = {i: r["prompt"].encode() + expected_text(nv, model_dir, r["prompt"], r["max_tokens"], True)
             for i, r in enumerate(reqs)}
-    for batch in ("1", "3"):
-        r = run(model_dir, "--input-json", str(path), "-b", batch)
+    for batch, sharding in (("1", ()), ("3", ()), ("1", ("--devices", "0,0")), ("2", ("--devices", "0,0,0"))):
+        # --devices a,b,...: the engine sequence-sharded, a model per entry (here all on GPU 0, standing in for several
+        # GPUs): each request still prints exactly the text it prints alone
+        r = run(model_dir, "--input-json", str(path), "-b", batch, *sharding)
         assert r.returncode == 0, r.stderr
+        if sharding:
+            assert b"sequence-sharded over" in r.stderr
         parts = (b"\n" + r.stdout).split(b"\n[request ")[1:]  # every request prints "[request i] prompt+text\n"
         assert parts and parts[-1].endswith(b"\n")
         parts[-1] = parts[-1][:-1]

@@ -257,7 +257,9 @@ std::vector<int> encode(const nvk_tokenizer *tok, const std::string &text)
 void usage()
 {
     fprintf(stderr, "usage: nvk_run <model dir | model.bin> (-i PROMPT | --input-json FILE) [-n STEPS] "
-                    "[-b MAX_BATCH] [-t TEMPERATURE (0, or any with --greedy)] [-p TOP_P] [--greedy] [--block-size N] [--num-blocks N] [--device N]\n");
+                    "[-b MAX_BATCH] [-t TEMPERATURE (0, or any with --greedy)] [-p TOP_P] [--greedy] [--block-size N] [--num-blocks N] [--device N]\n"
+                    "               [--gpus N | --devices a,b,...]   sequence-sharded over several GPUs: a model per device, -b requests each,\n"
+                    "               a request placed where the fewest tokens are promised; nothing exchanged between devices\n");
 }
 
 } // namespace
@@ -266,6 +268,7 @@ int main(int argc, char **argv)
 {
     std::string path, prompt, input_json;
     int         max_batch = 1, steps = 256, block_size = 16, num_blocks = 0, device = 0; // main.cpp:19-26, model.hpp:35-36
+    std::vector<int> devices; // --gpus N / --devices: the members of the sequence-sharded group (empty: one model on --device)
     float       temperature = 1.0f, top_p = 0.9f;
     bool        greedy = false; // --greedy: decode greedily whatever temperature a request asks for
     for (int a = 1; a < argc; a++) {
@@ -297,6 +300,22 @@ int main(int argc, char **argv)
             num_blocks = atoi(next());
         else if (k == "--device")
             device = atoi(next());
+        else if (k == "--gpus") {
+            const int n = atoi(next());
+            devices.clear();
+            for (int d = 0; d < n; d++)
+                devices.push_back(d);
+        }
+        else if (k == "--devices") { // explicit list; a device may appear twice (two members on one GPU)
+            devices.clear();
+            const std::string list = next();
+            for (size_t at = 0; at <= list.size();) {
+                const size_t comma = std::min(list.find(',', at), list.size());
+                if (comma > at)
+                    devices.push_back(atoi(list.substr(at, comma - at).c_str()));
+                at = comma + 1;
+            }
+        }
         else if (k == "--without-paged-attn") {
             fprintf(stderr, "[ERROR] --without-paged-attn: this build has only the paged path\n");
             return 1;
@@ -360,15 +379,27 @@ int main(int argc, char **argv)
     }
     if (num_blocks <= 0)
         num_blocks = std::max(256, max_batch * ((hdr[6] + block_size - 1) / block_size)); // Config::num_blocks = 256
-    nvk_model     *model = nullptr;
-    nvk_tokenizer *tok   = nullptr;
-    NVK_OR_DIE(nvk_model_load(model_path.c_str(), block_size, num_blocks, max_batch, device, &model));
+    // One code path for one device and for several: a group of one member is a model with a thread of its own.
+    if (devices.empty())
+        devices.push_back(device);
+    nvk_model_group *model = nullptr;
+    nvk_tokenizer   *tok   = nullptr;
+    NVK_OR_DIE(nvk_model_group_load(model_path.c_str(), block_size, num_blocks, max_batch, (int)devices.size(),
+                                    devices.data(), &model));
     int cfg[8];
-    NVK_OR_DIE(nvk_model_config(model, cfg));
+    NVK_OR_DIE(nvk_model_group_config(model, cfg));
     NVK_OR_DIE(nvk_tokenizer_load(tokenizer_path.c_str(), cfg[5], &tok));
     fprintf(stderr, "[INFO] %s: dim=%d layers=%d heads=%d/%d vocab=%d max_seq_len=%d; PagedAttention block_size=%d "
                     "num_blocks=%d; %s\n", model_path.c_str(), cfg[0], cfg[2], cfg[3], cfg[4], cfg[5], cfg[6], block_size,
             num_blocks, nvk_version());
+    if (devices.size() > 1) {
+        std::string list;
+        for (size_t i = 0; i < devices.size(); i++)
+            list += (i ? "," : "") + std::to_string(devices[i]);
+        fprintf(stderr, "[INFO] sequence-sharded over %zu members (devices %s), up to %d requests each, no collective\n",
+                devices.size(), list.c_str(), max_batch);
+    }
+    const int capacity = max_batch * (int)devices.size(); // running requests in all
 
     struct Running
     {
@@ -387,13 +418,16 @@ int main(int argc, char **argv)
     const auto t0 = std::chrono::high_resolution_clock::now();
     while (!running.empty() || next_request < requests.size()) {
         // admission (Scheduler::schedule: fill up to max_batch_size, scheduler.hpp:66-103)
-        while ((int)running.size() < max_batch && next_request < requests.size()) {
+        while ((int)running.size() < capacity && next_request < requests.size()) {
             Running r;
             r.id         = (int)next_request;
             r.prompt_ids = encode(tok, requests[next_request].prompt);
             if ((int)r.prompt_ids.size() >= cfg[6]) // keep room for at least one generated token
                 r.prompt_ids.resize((size_t)cfg[6] - 1);
-            NVK_OR_DIE(nvk_model_add_request(model, r.id));
+            // placed by promised tokens (prompt + max_tokens): the member with the least takes it
+            const int member = nvk_model_group_add_request(model, r.id, (int)r.prompt_ids.size() + requests[next_request].max_tokens);
+            if (member < 0)
+                NVK_OR_DIE(member);
             total_prompt += (long long)r.prompt_ids.size();
             running.push_back(std::move(r));
             next_request++;
@@ -417,7 +451,7 @@ int main(int argc, char **argv)
                 }
             }
         std::vector<int> next(ids.size());
-        NVK_OR_DIE(nvk_model_step_chunks(model, ids.data(), lens.data(), toks.data(), (int)ids.size(), next.data(), nullptr));
+        NVK_OR_DIE(nvk_model_group_step_chunks(model, ids.data(), lens.data(), toks.data(), (int)ids.size(), next.data(), nullptr));
         steps_run++;
         std::vector<int> done;
         for (size_t k = 0; k < ids.size(); k++) {
@@ -430,7 +464,7 @@ int main(int argc, char **argv)
             r.text += piece;
             if (single)
                 fputs(piece.c_str(), stdout), fflush(stdout);
-            const int len = nvk_model_request_len(model, r.id);
+            const int len = nvk_model_group_request_len(model, r.id);
             // request_processor.hpp:55-77: max_tokens, max_seq_len, EOS (2)
             if (r.generated >= requests[(size_t)r.id].max_tokens || len >= cfg[6] || (!single && next[k] == 2)) // runner.hpp:48-57 has no EOS stop
                 done.push_back(order[k]);
@@ -440,7 +474,7 @@ int main(int argc, char **argv)
             Running &r = running[(size_t)i];
             if (!single)
                 printf("[request %d] %s%s\n", r.id, requests[(size_t)r.id].prompt.c_str(), r.text.c_str());
-            NVK_OR_DIE(nvk_model_finish_request(model, r.id));
+            NVK_OR_DIE(nvk_model_group_finish_request(model, r.id));
             running.erase(running.begin() + i);
         }
     }
@@ -451,6 +485,6 @@ int main(int argc, char **argv)
                     "%.1f tokens/s\n", requests.size(), total_prompt, total_generated, steps_run, sec,
             sec > 0 ? total_generated / sec : 0.0);
     nvk_tokenizer_destroy(tok);
-    nvk_model_destroy(model);
+    nvk_model_group_destroy(model);
     return 0;
 }
