@@ -33,6 +33,12 @@
 #ifndef NVK_AUTO_MIN_CHUNK_WIDE
 #define NVK_AUTO_MIN_CHUNK_WIDE 32 // the same when the merge is nvk_merge_wide_kernel (few rows; tools/merge_sweep.sh)
 #endif
+#ifndef NVK_TINY_CHUNK_BYTES
+#define NVK_TINY_CHUNK_BYTES 0 // K + V bytes per workgroup up to which few rows are cut into <= 16 chunks so that the decode
+                               // kernel combines them itself (no merge launch).  Built and measured in round 3 with 256 KiB:
+                               // one TinyLlama request at 1K context 1.340 -> 1.393 ms per model step -- 16 workgroups of 64
+                               // tokens are slower than 32 of 32 plus the merge launch (profiles/r03_model_engine.log): off
+#endif
 #ifndef NVK_MERGE_WIDE_ROWS
 #define NVK_MERGE_WIDE_ROWS 1024 // (rows x q-heads) up to which the merge runs one workgroup per (row, head); at 2048
                                  // (64 rows x 32 heads, 4 chunks) the two forms measure 5.5 and 5.1 us
@@ -394,6 +400,13 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
         // long sequence alone, 32K tokens: 171 us with 256 chunks of 128, 134 us with 128 chunks of 256), and
         // nvk_merge_wide_kernel holds one chunk per thread
         chunk = std::max<long long>(chunk, round_up((ctx_cap + most - 1) / most, min_chunk));
+        // (A/B knob, off: few rows cut into no more chunks than the decode kernel combines itself, so that the merge
+        // launch goes away -- measured slower, see NVK_TINY_CHUNK_BYTES)
+        if (wide && NVK_TINY_CHUNK_BYTES > 0 && !(mods & NVK_DECODE_MERGE_SEPARATE)) {
+            const long long fused = round_up((ctx_cap + NVK_FUSE_MAX_CHUNKS - 1) / NVK_FUSE_MAX_CHUNKS, step);
+            if (fused > chunk && fused * 2 * pool->row_len() * (long long)sizeof(float) <= NVK_TINY_CHUNK_BYTES)
+                chunk = fused;
+        }
     }
     chunk = std::min<long long>(chunk, ctx_cap);
     chunk = std::min<long long>(chunk, slice_cap);
