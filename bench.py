@@ -895,6 +895,9 @@ def main():
     ap.add_argument("--free-running", action="store_true",
                     help="diagnostic: the vector kernel without the lockstep barrier and with 8-token steps "
                          "(NVK_DECODE_FREE_RUNNING)")
+    ap.add_argument("--row-pairs", action="store_true",
+                    help="diagnostic: whole 128-float rows as kv-head pairs in 4-wave workgroups, two to a CU "
+                         "(NVK_DECODE_ROW_PAIRS)")
     ap.add_argument("--no-extra", action="store_true",
                     help="N=1 only: skip the extra BASELINE configs (3, 4, 5a, 5b) timed after the headline workload")
     ap.add_argument("--extra-timeout", type=float, default=150.0,
@@ -937,6 +940,8 @@ def main():
         flags |= nv.NO_PAIRS
     if args.free_running:
         flags |= nv.FREE_RUNNING
+    if args.row_pairs:
+        flags |= nv.ROW_PAIRS
     uniform_batch = bool((work.ctx_lens == work.ctx_lens[0]).all())
     if args.plan == "none" or (args.plan == "auto" and uniform_batch):
         flags |= nv.UNIFORM if uniform_batch else nv.NO_PLAN

@@ -74,6 +74,11 @@ extern "C" {
  * (the code path of pools with more kv-heads than a workgroup has waves), where it exists: same bits for 8-token-step
  * shapes, same tolerance otherwise (A/B, tests). */
 #define NVK_DECODE_FREE_RUNNING 0x4000
+/* Whole 128-float rows of up to 8 kv-heads (an even number, up to 4 q-heads each) as a PAIR of kv-heads per wave in
+ * 4-wave workgroups, two of which fit a CU: a workgroup's successor then starts beside a running one instead of behind
+ * it.  For launches made of many short sequences (generations of workgroups, each paying its start and its end).
+ * Same arithmetic per head; tokens meet in another order (same tolerance, not the same bits). */
+#define NVK_DECODE_ROW_PAIRS 0x8000
 
 /* prefill flags */
 #define NVK_PREFILL_AUTO 0    /* library picks by chunk length                                      */

@@ -30,6 +30,7 @@ DECODE_NO_PLAN = 0x800
 DECODE_VECTOR_ONLY = 0x1000
 DECODE_NO_PAIRS = 0x2000
 DECODE_FREE_RUNNING = 0x4000
+DECODE_ROW_PAIRS = 0x8000
 
 PREFILL_AUTO = 0
 PREFILL_ROWWISE = 1

@@ -29,6 +29,7 @@ NO_PLAN = _capi.DECODE_NO_PLAN
 VECTOR_ONLY = _capi.DECODE_VECTOR_ONLY
 NO_PAIRS = _capi.DECODE_NO_PAIRS
 FREE_RUNNING = _capi.DECODE_FREE_RUNNING
+ROW_PAIRS = _capi.DECODE_ROW_PAIRS
 
 
 def bind_pool(pool: Optional[PagedKVPool], layer: int = 0) -> None:

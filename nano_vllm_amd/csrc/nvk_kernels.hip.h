@@ -442,7 +442,8 @@ template <int VPL, int QPK, bool FULL, int KPW, bool LOCK, bool WIDE = false>
 __device__ __forceinline__ void decode_body(const DecodeParams &p)
 {
     static_assert(!WIDE || (VPL == 2 && QPK <= 4 && FULL && KPW == 1), "16-token steps: registers were counted for these");
-    static_assert(KPW == 1 || (KPW == 2 && VPL == 1 && !FULL), "kv-head pairs are for short odd rows only");
+    static_assert(KPW == 1 || (KPW == 2 && ((VPL == 1 && !FULL) || (VPL == 2 && FULL && QPK <= 4))),
+                  "kv-head pairs: short odd rows, or whole 128-float rows in 4-wave workgroups (NVK_DECODE_ROW_PAIRS)");
     constexpr int  kTokPerLane = WIDE ? 4 : tok_per_lane(VPL, QPK); // tokens each lane holds per step
     constexpr int  kSlots      = 4 / KPW;                      // token slots of a wave (16-lane rows per kv-head)
     constexpr int  kStepTokens = 4 * kTokPerLane / KPW;        // tokens per wave per pipeline step
@@ -688,8 +689,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams &p)
     // runs (token parts differ by at most one step).  Not for 256-float rows (one wave per SIMD: nothing drifts;
     // measured 3 % slower), nor for 8 q-heads over whole 64-float rows (the MFMA kernel's shape unless
     // NVK_DECODE_VECTOR_ONLY forces this one: the branch costs the instantiation its last registers).
-    constexpr bool kLock = LOCK && NVK_LOCKSTEP && KPW == 1 && VPL < 4 && !(VPL == 1 && QPK == 8 && FULL);
-    const int locked_upto = kLock && p.n_kv_heads == p.kv_waves
+    constexpr bool kLock = LOCK && NVK_LOCKSTEP && (KPW == 1 || VPL == 2) && VPL < 4 && !(VPL == 1 && QPK == 8 && FULL);
+    const int locked_upto = kLock && p.n_kv_heads == p.kv_waves * KPW
                                 ? (t1 - t0 + kStepTokens - 1) / kStepTokens / parts // steps of the part with the fewest
                                 : 0;
     if (has_tokens) {
@@ -913,6 +914,16 @@ __global__ void __launch_bounds__(64 * wg_waves(1, QPK, false), NVK_MIN_WAVES_PE
     nvk_decode_pairs_kernel(const DecodeParams p)
 {
     decode_body<1, QPK, false, 2, false>(p);
+}
+
+// whole 128-float rows, a PAIR of adjacent kv-heads per wave, 4 waves per workgroup (NVK_DECODE_ROW_PAIRS): the
+// workgroup still holds every kv-head of its token rows (8 kv-heads), but two of them fit a CU, so a workgroup's
+// successor starts beside a running one instead of behind it -- for batches of many short sequences, whose launch
+// is generations of workgroups each paying its start and its end with the CU idle
+template <int QPK>
+__global__ void __launch_bounds__(256, 2) nvk_decode_rowpairs_kernel(const DecodeParams p)
+{
+    decode_body<2, QPK, true, 2, true>(p);
 }
 
 // ---- the decode kernel on fp32 MFMA tiles, for GQA groups of 5..16 q-heads --------------------------------

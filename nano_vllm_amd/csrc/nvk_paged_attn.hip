@@ -295,6 +295,7 @@ struct LaunchShape
     bool mfma        = false; // nvk_decode_mfma_kernel: one wave carries the whole GQA group on 16-token MFMA tiles
     int  kpw         = 1;     // kv-heads per wave: 2 where a row is an odd number of half-lines (head_dim 16 / 48)
     bool wide        = false; // nvk_decode_wide_kernel: 16-token steps (long chunks of whole 128-float rows, no token parts)
+    bool row_pairs   = false; // NVK_DECODE_ROW_PAIRS: nvk_decode_rowpairs_kernel (128-float rows, kv-head pairs, 4 waves)
     bool free_forced = false; // NVK_DECODE_FREE_RUNNING: nvk_decode_free_kernel (no lockstep, 8-token steps) wherever it exists
     size_t lds_bytes = 0;
     int  qgroups     = 1;     // (kv-head group, q sub-group) pairs per item = arrival counters per row
@@ -309,7 +310,7 @@ bool decode_flags_ok(int flags)
     if (mode != NVK_DECODE_AUTO && mode != NVK_DECODE_SINGLE_PASS && mode != NVK_DECODE_SPLIT_K)
         return false;
     if (mods & ~(NVK_DECODE_MERGE_IN_KERNEL | NVK_DECODE_MERGE_SEPARATE | NVK_DECODE_UNIFORM | NVK_DECODE_NO_PLAN
-                 | NVK_DECODE_VECTOR_ONLY | NVK_DECODE_NO_PAIRS | NVK_DECODE_FREE_RUNNING))
+                 | NVK_DECODE_VECTOR_ONLY | NVK_DECODE_NO_PAIRS | NVK_DECODE_FREE_RUNNING | NVK_DECODE_ROW_PAIRS))
         return false;
     return !((mods & NVK_DECODE_MERGE_IN_KERNEL) && (mods & NVK_DECODE_MERGE_SEPARATE));
 }
@@ -344,13 +345,18 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
                  && !(mods & NVK_DECODE_VECTOR_ONLY);
     if (plan->mfma)
         plan->qpk = kv_mul;
-    const int wg_waves = plan->mfma ? 8 : std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl, plan->qpk, plan->full));
+    // whole 128-float rows as kv-head pairs in 4-wave workgroups, two to a CU (asked for by the caller: short ragged batches)
+    plan->row_pairs = (mods & NVK_DECODE_ROW_PAIRS) && !plan->mfma && plan->vpl == 2 && plan->full && plan->qpk <= 4
+                      && plan->qpk == kv_mul && pool->n_kv_heads % 2 == 0 && pool->n_kv_heads <= 8;
+    const int wg_waves = plan->mfma ? 8 : plan->row_pairs ? 4 : std::min(NVK_WG_WAVES, nvk::wg_waves(plan->vpl, plan->qpk, plan->full));
     // rows of 64 or 192 B (head_dim 16 / 48) share their 128-B lines with the neighbour kv-head: a wave then takes
     // the PAIR of heads (whole lines per token, each requested once); needs token rows that start on a line
     plan->kpw = (NVK_KV_PAIRS && plan->vpl == 1 && hd % 32 == 16 && pool->n_kv_heads % 2 == 0 && plan->qpk <= 4
                  && !(mods & NVK_DECODE_NO_PAIRS))
                     ? 2
                     : 1;
+    if (plan->row_pairs)
+        plan->kpw = 2;
     const int kv_slots = pool->n_kv_heads / plan->kpw; // waves along the kv axis in all
     plan->waves      = std::min(kv_slots, wg_waves);
     plan->kv_groups  = (kv_slots + plan->waves - 1) / plan->waves;
@@ -487,6 +493,15 @@ template <int VPL> hipError_t launch_decode_qpk(int qpk, bool full, bool free_ru
 
 hipError_t launch_decode(const LaunchShape &plan, dim3 grid, dim3 block, hipStream_t stream, const nvk::DecodeParams &p)
 {
+    if (plan.row_pairs) { // make_shape: vpl 2, full, at most 4 q-heads per wave, kv-head pairs
+        switch (plan.qpk) {
+        case 4: hipLaunchKernelGGL((nvk::nvk_decode_rowpairs_kernel<4>), grid, block, plan.lds_bytes, stream, p); break;
+        case 3: hipLaunchKernelGGL((nvk::nvk_decode_rowpairs_kernel<3>), grid, block, plan.lds_bytes, stream, p); break;
+        case 2: hipLaunchKernelGGL((nvk::nvk_decode_rowpairs_kernel<2>), grid, block, plan.lds_bytes, stream, p); break;
+        default: hipLaunchKernelGGL((nvk::nvk_decode_rowpairs_kernel<1>), grid, block, plan.lds_bytes, stream, p); break;
+        }
+        return hipGetLastError();
+    }
     if (plan.kpw == 2) { // make_shape: vpl 1, not full, at most 4 q-heads per wave
         switch (plan.qpk) {
         case 4: hipLaunchKernelGGL((nvk::nvk_decode_pairs_kernel<4>), grid, block, plan.lds_bytes, stream, p); break;
@@ -1964,6 +1979,8 @@ int nvk_decode_kernel_name(nvk_pool *pool, int num_seqs, int n_heads, int max_ct
         return rc;
     if (sh.mfma)
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_mfma_kernel<%d>", 64 * sh.vpl);
+    else if (sh.row_pairs)
+        snprintf(buf, (size_t)cap, "nvk::nvk_decode_rowpairs_kernel<%d>", sh.qpk);
     else if (sh.kpw == 2)
         snprintf(buf, (size_t)cap, "nvk::nvk_decode_pairs_kernel<%d>", sh.qpk);
     else if (sh.wide)

@@ -71,3 +71,41 @@ def test_paired_heads_full_size_tiny_geometry():
         assert_close(a[sample], want, "5b tiny, pairs")
         assert np.abs(a).max() <= 1.0 and np.isfinite(a).all()
         assert_close(a, b, "pairs vs single heads")
+
+
+# NVK_DECODE_ROW_PAIRS: whole 128-float rows, a pair of kv-heads per wave, 4-wave workgroups (two to a CU)
+ROW_PAIR_GEOMS = [(32, 8, 128, 16), (8, 8, 128, 16), (12, 4, 128, 8), (4, 2, 128, 16), (24, 8, 128, 32), (16, 8, 128, 1)]
+
+
+@pytest.mark.parametrize("geom", ROW_PAIR_GEOMS, ids=[f"H{g[0]}_KV{g[1]}_hd{g[2]}_bs{g[3]}" for g in ROW_PAIR_GEOMS])
+def test_row_pairs_against_checker_and_the_default_kernel(geom):
+    """nvk_decode_rowpairs_kernel<QPK> is held to the bar of the kernel it replaces: the CPU checker on ragged
+    fragmented batches in every mode, token-split shapes (2 / 4 kv-heads: the spare waves split the tokens) included,
+    and in-kernel combine == merge kernel bit for bit."""
+    g = wl.Geometry(*geom)
+    ctx = np.array([1, 3, 4, 5, 15, 16, 17, 31, 33, 300, 1027, 0, 64, 2048, 129], np.int32)
+    work = wl.fragmented_workload("rowpairs", ctx, g, perm_seed=7)
+    q = work.q() * np.float32(2.0)
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(work.num_seqs)))
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, g.block_size, g.n_kv_heads, n_threads=8)
+    with nv.PagedKVPool(1, work.num_blocks, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        name = nv.decode_kernel_name(pool, work.num_seqs, g.n_heads, 2048, nv.ROW_PAIRS)
+        assert name.startswith("nvk::nvk_decode_rowpairs_kernel<"), name
+        for flags, chunk in ((nv.AUTO, 0), (nv.SINGLE_PASS, 0), (nv.SPLIT_K, 48), (nv.SPLIT_K | nv.NO_PLAN, 16),
+                             (nv.SPLIT_K, 1024)):
+            got = nv.decode(pool, 0, q, work.block_tables, ctx, flags | nv.ROW_PAIRS, chunk)
+            assert_close(got, want, f"{geom} row pairs flags=0x{flags:x} chunk={chunk}")
+        fused = nv.decode(pool, 0, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_IN_KERNEL | nv.ROW_PAIRS, 64)
+        apart = nv.decode(pool, 0, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_SEPARATE | nv.ROW_PAIRS, 64)
+        assert same_bits(fused, apart), f"{geom}: in-kernel combine vs merge kernel"
+        assert not got[11].any()  # ctx 0 -> zero row (attention.hpp:98)
+
+
+def test_row_pairs_is_declined_where_it_has_no_kernel():
+    """Odd kv-head counts, other row widths, GQA groups past 4 q-heads per wave: the modifier is accepted and the
+    default kernel runs."""
+    for geom in ((9, 3, 128, 16), (32, 8, 64, 16), (64, 8, 128, 16), (32, 32, 128, 16)):
+        g = wl.Geometry(*geom)
+        with nv.PagedKVPool(1, 64, g.block_size, g.n_kv_heads, g.head_dim) as pool:
+            assert "rowpairs" not in nv.decode_kernel_name(pool, 4, g.n_heads, 512, nv.ROW_PAIRS), geom
