@@ -68,6 +68,12 @@
 #ifndef NVK_SKINNY16_MAX_ROWS
 #define NVK_SKINNY16_MAX_ROWS 16 // up to here the weight-streaming kernel uses 16 x 16 MFMA tiles (0: always 32 x 32)
 #endif
+#ifndef NVK_SKINNY16_BALANCED
+#define NVK_SKINNY16_BALANCED 1 // 16-row tiles: output columns dealt evenly over the CUs (nvk_gemm_skinny16_kernel); 0: 16-column tiles
+#endif
+#ifndef NVK_SKINNY16_BK
+#define NVK_SKINNY16_BK 64 // k-step of the 16 x 16 tile kernel without an epilogue (32: half the LDS per workgroup, twice the steps)
+#endif
 #ifndef NVK_SKINNY16_TM2
 #define NVK_SKINNY16_TM2 0 // 1: 17-32 rows on 16 x 16 tiles with both row tiles in one wave (weights cross L2 once).  Built and measured in
                            // round 3: 32.3 us against 33.0 at 6144 columns -- the kernel is not bound by the second reading -- not kept
@@ -107,6 +113,7 @@ struct LinearParams
     int          m, k, lda;
     LinearSeg    seg[3];
     int          nseg, n_tiles, m_tiles;
+    int          cw; // nvk_gemm_skinny16_kernel: output columns per workgroup (a multiple of 4)
     RopeAppendTarget rope; // nvk_gemv_kernel<.., ROPE>: where the q / k / v epilogue writes
     NormLink         link; // nvk_gemv_kernel<.., SCALE / RESID>: the norm carried from one GEMV to the next
 };
@@ -652,6 +659,155 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
     }
 }
 
+// ---- the same for up to 16 rows per row tile, with the output columns dealt EVENLY over the CUs ---------------
+// A launch of the kernel above takes as long as its busiest CU: 6144 columns in 16-column tiles are 384 workgroups,
+// 1.5 per CU, and run as long as 8192 columns do (23.3 against 25.2 us; 4096 columns: 13.3).  Here a workgroup takes
+// `cw` columns (a multiple of 4, at most 16 TN; p.cw, chosen by the host so that the launch is whole rounds of one
+// workgroup per CU) as TN MFMA tiles of 16 that share each activation tile; weight rows past the workgroup's columns
+// and activation rows past m are not loaded; four weight tiles in flight per wave (two at TN > 1).
+// Otherwise nvk_gemm_skinny_kernel<16, 1, 64>: 8 waves deal the contraction in steps of 64, each through its own LDS
+// region, partial tiles meet in LDS.  EPI: plain or RoPE + append.
+// What this kernel is bound by (profiles/r03_skinny_balance.log): 3.3 us + 1.2 us per 512 of k per workgroup, whatever
+// the rows (3 or 16), the columns per workgroup (8 or 16) and the tiles in flight (2 or 4) -- a wave-step is 8 loads,
+// 16 LDS instructions and 16 MFMAs, each about 0.4 us per round of the CU's eight waves, one after the other within a
+// wave.  The same contraction with the MFMA operands loaded straight from memory in the operand's layout (16 rows x
+// 64 B per instruction, no LDS) was built, is bit-for-bit as good against the checker, and is SLOWER at 16 rows
+// (wo 8.1 -> 10.2 us, down 16.5 -> 20.9): twice the cache lines per load instruction.  Not kept.
+template <int TN, int EPI>
+__global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny16_kernel(const LinearParams p)
+{
+    static_assert(EPI == kSkinnyPlain || EPI == kSkinnyRope, "epilogues here: none, or RoPE + append");
+    constexpr int T = 16, BK = 64, LDS = BK + 4, LPR = BK / 4, RPI = 64 / LPR; // 16 lanes a tile row, 4 rows an instruction
+    constexpr int RX = T / RPI, RW = TN * T / RPI;                             // float4 per lane per step
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];              // [waves][(1 + TN) * 16][LDS]
+    const int span = 8 * p.m_tiles;
+    const int rem  = blockIdx.x % span;
+    const int nt   = blockIdx.x / span * 8 + rem % 8;
+    const int m0   = rem / 8 * T;
+    if (nt >= p.n_tiles)
+        return;
+    const LinearSeg sg = segment_of(p, nt);
+    const int       n0 = (nt - sg.tile0) * p.cw, n1 = min(n0 + p.cw, sg.n); // this workgroup's columns [n0, n1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, part = lane >> 4;
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+
+    constexpr int kRegion = (1 + TN) * T * LDS;
+    float        *sa = s_mem + wave * kRegion, *sb = sa + T * LDS;
+    int           aoff[RX], woff[RW];
+    bool          wlive[RW], xlive[RX];
+#pragma unroll
+    for (int i = 0; i < RX; i++) {
+        xlive[i] = m0 + lr + RPI * i < p.m;
+        aoff[i]  = min(m0 + lr + RPI * i, p.m - 1) * p.lda + lc;
+    }
+#pragma unroll
+    for (int i = 0; i < RW; i++) {
+        wlive[i] = n0 + lr + RPI * i < n1;
+        woff[i]  = min(n0 + lr + RPI * i, sg.n - 1) * p.k + lc;
+    }
+    constexpr int D = TN == 1 ? 4 : 2; // weight tiles in flight per wave: 16 KiB (24 at TN 3)
+    float4 rx[2][RX], rw[D][RW];
+    auto   fetch_w = [&](float4(&r)[RW], int k0) {
+        const bool inside = k0 + lc < p.k;
+#pragma unroll
+        for (int i = 0; i < RW; i++)
+            r[i] = inside && wlive[i] ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto fetch_x = [&](float4(&r)[RX], int k0) {
+        const bool inside = k0 + lc < p.k;
+#pragma unroll
+        for (int i = 0; i < RX; i++)
+            r[i] = inside && xlive[i] ? *reinterpret_cast<const float4 *>(p.a + aoff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](const float4(&x)[RX], const float4(&r)[RW]) {
+#pragma unroll
+        for (int i = 0; i < RX; i++)
+            *reinterpret_cast<float4 *>(sa + (lr + RPI * i) * LDS + lc) = x[i];
+#pragma unroll
+        for (int i = 0; i < RW; i++)
+            *reinterpret_cast<float4 *>(sb + (lr + RPI * i) * LDS + lc) = r[i];
+    };
+    f32x4 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; t++)
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *pa = sa + j * LDS + 4 * part, *pb = sb + j * LDS + 4 * part;
+    auto         multiply = [&]() {
+#pragma unroll
+        for (int c = 0; c < BK / 16; c++) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(pa + 16 * c);
+#pragma unroll
+            for (int t = 0; t < TN; t++) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(pb + t * T * LDS + 16 * c);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    const int nk    = (p.k + BK - 1) / BK;
+    const int steps = nk > wave ? (nk - wave + kSkinnyWaves - 1) / kSkinnyWaves : 0;
+    // (the walk over k starts at a tile that depends on the column tile only: see nvk_gemm_skinny_kernel)
+    const int rot   = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
+    auto      k_of  = [&](int s) { return ((wave + s * kSkinnyWaves + rot) % nk) * BK; };
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        if (d < steps)
+            fetch_w(rw[d], k_of(d));
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+        if (d < steps)
+            fetch_x(rx[d], k_of(d));
+    for (int s = 0; s < steps; s += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) // (D is even: step s + d uses activation buffer d & 1)
+            if (s + d < steps) {
+                stash(rx[d & 1], rw[d]);
+                if (s + d + D < steps)
+                    fetch_w(rw[d], k_of(s + d + D));
+                if (s + d + 2 < steps)
+                    fetch_x(rx[d & 1], k_of(s + d + 2));
+                multiply();
+            }
+    }
+    // the waves' partial tiles meet in LDS (own regions), then TN x 64 threads add the eight partials of four outputs
+    // each, in wave order: D[row][col], col = lane % 16, register r of lane part p holds row 4 p + r
+    static_assert(TN * 4 * 64 <= kRegion, "the reduction does not fit the wave's LDS region");
+#pragma unroll
+    for (int t = 0; t < TN; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            sa[(t * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    if (tid < TN * 64) {
+        const int t = tid >> 6, r = (tid >> 4) & 3, l4 = (tid & 15) * 4;
+        const int row = m0 + 4 * (l4 / T) + r, col = n0 + t * T + (l4 & (T - 1));
+        float4    sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < kSkinnyWaves; w++) {
+            const float4 v = *reinterpret_cast<const float4 *>(s_mem + w * kRegion + (t * 4 + r) * 64 + l4);
+            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+        }
+        if (row < p.m && col < n1) {
+            float *o = sg.out + (int64_t)row * sg.ldo + col;
+            if (EPI == kSkinnyRope) { // (the host checked n % 4 == 0 and cw % 4 == 0: a float4 is in or out)
+                const int si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
+                rope_append_store(p.rope, si, row, col, sum, o);
+            }
+            else if (col + 3 < n1 && (sg.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.out) & 15) == 0))
+                *reinterpret_cast<float4 *>(o) = sum;
+            else {
+                o[0] = sum.x;
+                if (col + 1 < n1) o[1] = sum.y;
+                if (col + 2 < n1) o[2] = sum.z;
+                if (col + 3 < n1) o[3] = sum.w;
+            }
+        }
+    }
+}
+
 // ---- C = A . W^T, one or two rows: the reference's own case (one token: Ops::matmul is a GEMV) -------
 // HBM-bound: every weight byte is read once and multiplied on the vector ALUs (an MFMA tile padded to 32
 // rows would cost as much time as the stream itself).  One workgroup = kGemvCols output columns (weight rows: 4),
@@ -956,6 +1112,25 @@ bool tile16(int batch, const int *n, int nseg, int cus)
            || (NVK_SKINNY16_WIDE && batch <= 64 && t32 <= cus / 4);
 }
 
+// Output columns per workgroup of nvk_gemm_skinny16_kernel (a multiple of 4 in [8, 48]): the fewest rounds of one
+// workgroup per CU that the columns fit in, and within that round count the narrowest workgroups -- a launch takes as
+// long as its busiest CU (see the kernel), so every CU gets the same share wherever the output is wide enough.
+int balanced_cols(int batch, const int *n, int nseg, int cus)
+{
+    const int m_tiles = (batch + 15) / 16;
+    auto      wgs_at  = [&](int cw) {
+        long long t = 0;
+        for (int s = 0; s < nseg; s++)
+            t += (n[s] + cw - 1) / cw;
+        return t * m_tiles;
+    };
+    for (int rounds = 1; rounds <= 64; rounds++)
+        for (int cw = 8; cw <= 48; cw += 4)
+            if (wgs_at(cw) <= (long long)rounds * cus)
+                return cw;
+    return 48;
+}
+
 // the weight-streaming kernel's tile (16 or 32) and row tiles per wave for `batch` rows
 void skinny_choice(int batch, const int *n, int nseg, int cus, int *t, int *tm, bool epilogue = false)
 {
@@ -1038,6 +1213,23 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     }
     else
         bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (t16 ? 16 : 32);
+    // 16-row tiles without a norm link: the columns dealt evenly over the CUs (nvk_gemm_skinny16_kernel), `cw` to a workgroup
+    // ... only where 16-column tiles leave the chip visibly unbalanced (the busiest CU 1.25 x the mean or more: 6144
+    // columns are 1.5 workgroups per CU and run as long as 8192).  Elsewhere the 16-column kernel is as fast or faster
+    // (TinyLlama's 2048-wide shapes, whole model step: 1.72 against 1.82 ms at 4 requests, profiles/r03_skinny_balance.log)
+    bool balanced = NVK_SKINNY16_BALANCED && !gemv && skinny && t16 && sk_tm == 1 && !link;
+    {
+        long long t16s = 0;
+        for (int s = 0; s < nseg; s++)
+            t16s += (n[s] + 15) / 16;
+        t16s *= (batch + 15) / 16;
+        const long long rounds = (t16s + cus - 1) / cus;
+        balanced = balanced && t16s > cus && rounds * cus * 4 >= t16s * 5;
+    }
+    for (int s = 0; s < nseg; s++)
+        balanced = balanced && n[s] % 4 == 0; // (its workgroups own whole float4s of a row)
+    if (balanced)
+        bn = balanced_cols(batch, n, nseg, cus);
     long long tiles = 0;
     p.nseg = 0;
     for (int s = 0; s < nseg; s++) {
@@ -1084,15 +1276,42 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     }
     else if (skinny) {
         // 16 x 16 tiles up to 16 rows; 32 x 32 up to 32; above, one wave carries 2 or 3 row tiles of 32 (NVK_SKINNY_TM)
-        const int t  = bn;
+        const int t  = balanced ? 16 : bn; // (balanced: bn is the workgroup's column count, the row tile stays 16)
         const int tm = sk_tm;
-        const int bk = tm > 1 ? 32 : 64;
+        const int bk = (tm > 1 || (t == 16 && NVK_SKINNY16_BK == 32 && !rope && !link)) ? 32 : 64;
         p.m_tiles = tm > 1 ? 1 : (batch + t - 1) / t;
         const long long wgs = p.m_tiles == 1 ? tiles : (tiles + 7) / 8 * 8 * p.m_tiles;
         if (wgs > 0x7fffffffLL)
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
         const size_t lds = (size_t)nvk::kSkinnyWaves * (tm + 1) * t * (bk + 4) * sizeof(float);
         const dim3 block(64 * nvk::kSkinnyWaves);
+        if (balanced) {
+            const int tn = (bn + 15) / 16;
+            p.cw         = bn;
+            const size_t lds16 = (size_t)nvk::kSkinnyWaves * (1 + tn) * 16 * (64 + 4) * sizeof(float);
+            const dim3   grid((unsigned)wgs);
+#define NVK_SK16(TN_)                                                                                                  \
+    do {                                                                                                               \
+        const void *fn16 = rope ? (const void *)nvk::nvk_gemm_skinny16_kernel<TN_, nvk::kSkinnyRope>                   \
+                                : (const void *)nvk::nvk_gemm_skinny16_kernel<TN_, nvk::kSkinnyPlain>;                  \
+        int rc16 = opt_in_lds(fn16, lds16, device);                                                                    \
+        if (rc16 != NVK_OK)                                                                                            \
+            return rc16;                                                                                               \
+        if (rope)                                                                                                      \
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny16_kernel<TN_, nvk::kSkinnyRope>), grid, block, lds16, st, p);     \
+        else                                                                                                           \
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny16_kernel<TN_, nvk::kSkinnyPlain>), grid, block, lds16, st, p);    \
+    } while (0)
+            if (tn == 1)
+                NVK_SK16(1);
+            else if (tn == 2)
+                NVK_SK16(2);
+            else
+                NVK_SK16(3);
+#undef NVK_SK16
+            HIP_TRY(hipGetLastError());
+            return NVK_OK;
+        }
         if (rope || link) { // the 16 x 16 tile kernel with an epilogue (checked above)
             using namespace nvk;
             const void *fused =
@@ -1119,6 +1338,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             return NVK_OK;
         }
         const void  *fn  = t == 16 ? (tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 2, 32>
+                                      : bk == 32 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 32>
                                               : (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 64>)
                            : tm == 1 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 1, 64>
                            : tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<32, 2, 32>
@@ -1129,6 +1349,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         const dim3 grid((unsigned)wgs);
         if (t == 16 && tm == 2)
             hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 2, 32>), grid, block, lds, st, p);
+        else if (t == 16 && bk == 32)
+            hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 1, 32>), grid, block, lds, st, p);
         else if (t == 16)
             hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 1, 64>), grid, block, lds, st, p);
         else if (tm == 1)

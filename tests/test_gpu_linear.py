@@ -92,7 +92,11 @@ def test_residual_add_fused_into_the_norm(nv, DA):
 @pytest.mark.parametrize("B,D,N", [(1, 4096, 4096), (4, 288, 288), (32, 1024, 100), (33, 1024, 100), (17, 100, 33),
                                     (128, 512, 384), (129, 260, 130), (300, 64, 1), (2, 4, 3),
                                     # 17-32 rows over >= 256 column tiles: two 16-row tiles per weight tile (<16, 2, 32>)
-                                    (17, 512, 4100), (24, 1028, 4096), (32, 260, 5000), (31, 4096, 6144)])
+                                    (17, 512, 4100), (24, 1028, 4096), (32, 260, 5000), (31, 4096, 6144),
+                                    # 3-16 rows: output columns dealt evenly over the CUs, 8 .. 48 to a workgroup
+                                    # (nvk_gemm_skinny16_kernel<1 | 2 | 3>), ragged last workgroups and k tails
+                                    (16, 4096, 6144), (3, 2048, 2048), (9, 260, 11264), (16, 64, 12), (5, 132, 4104),
+                                    (13, 1024, 20), (16, 2048, 32000), (20, 256, 9000)])
 def test_matmul_shapes_against_the_checker(B, D, N, nv, DA):
     """Both kernels (<= 32 rows: weights streamed once; more: 128x128 MFMA tiles), ragged edges in every dimension."""
     x = uniform(900 + B, 0, B * D).reshape(B, D)

@@ -37,7 +37,7 @@ def main():
                         "launches_WRITE_SIZE": len(w), "hbm_bytes_per_launch_corrected": int(round((2 * fm + wm) * 1024))}
     print(json.dumps({
         "round": int(rnd),
-        "command": "tools/profile_workload.sh: rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-extra --rotate 1 --prewarm-ms 0 <workload args> ; "
+        "command": "tools/profile_workload.sh: rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-extra --no-frows --rotate 1 --prewarm-ms 0 <workload args> ; "
                    "same with --pmc WRITE_SIZE (one counter per pass)",
         "workload": workload,
         "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; gfx950 correction (MI355X_MICROARCH.md, HBM): "

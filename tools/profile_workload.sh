@@ -11,14 +11,14 @@ tag="$1"; args="$2"
 out=gpurun_out/prof_r02/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-common="--no-cpu --no-extra --rotate 1 --prewarm-ms 0 $args"
+common="--no-cpu --no-extra --no-frows --rotate 1 --prewarm-ms 0 $args"
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- python3 bench.py --steps 20 --warmup 5 $common > "$out/stats.log" 2>&1 || { echo "stats pass failed"; tail -5 "$out/stats.log"; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o fetch -- python3 bench.py --steps 5 --warmup 2 $common > "$out/fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$out/fetch.log"; exit 1; }
 timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o write -- python3 bench.py --steps 5 --warmup 2 $common > "$out/write.log" 2>&1 || { echo "write pass failed"; tail -5 "$out/write.log"; exit 1; }
 name=$(grep -o '"workload": "[^"]*"' "$out/stats.log" | head -1 | sed 's/.*: "//; s/"//')
 f=$(find "$out/fetch" -name '*counter_collection.csv' | head -1)
 w=$(find "$out/write" -name '*counter_collection.csv' | head -1)
-python3 tools/pmc_traffic.py "$f" "$w" "$name" 2 > "$out/${tag}_pmc_traffic.json"
+python3 tools/pmc_traffic.py "$f" "$w" "$name" 3 > "$out/${tag}_pmc_traffic.json"
 k=$(find "$out/stats" -name '*kernel_stats.csv' | head -1)
 cp "$k" "$out/${tag}_kernel_stats.csv"
 grep '^{' "$out/stats.log" | tail -1 > "$out/${tag}_bench_under_rocprof.json"
