@@ -426,11 +426,12 @@ def projection_rows(nv, torch, dev, ev, args):
                "ref": "include/core/model.hpp:164-166, include/ops/linear.hpp:12-22", "calls_per_region": 30,
                "regions": 5, "ms_per_call": round(ms, 5), "ms_per_call_min": round(ms_min, 5), "checked": checked}
         if rows <= 32:
-            row.update({"bound": "hbm", "kernel": "nvk::nvk_gemv_kernel" if rows <= 2 else "nvk::nvk_gemm_skinny_kernel",
+            row.update({"bound": "hbm", "kernel": ("nvk::nvk_gemv_kernel<1, 4, 2, false, false, false, false>" if rows <= 2 else
+                                                   "nvk::nvk_gemm_skinny16_kernel<2, 0>"),
                         "algorithmic_bytes": wbytes, "GBps": round(wbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                         "frac": round(wbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
         else:
-            row.update({"bound": "mfma", "kernel": "nvk::nvk_gemm_nt_kernel", "algorithmic_flops": flops,
+            row.update({"bound": "mfma", "kernel": "nvk::nvk_gemm_nt_kernel<64, 64, 32>", "algorithmic_flops": flops,
                         "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                         "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)})
         res[f"qkv_{rows}row" if rows == 1 else f"qkv_{rows}rows"] = row
@@ -474,7 +475,8 @@ def model_step_rows(nv, torch, dev, args):
         res = {}
         with nv.LlamaModel(path, bs, blocks, max_seqs=64, device=dev.index) as m:
             os.unlink(path)  # resident in HBM now
-            for n_req in (1, 64):
+            for n_req, linked in ((1, False), (1, True), (64, False)):
+                m.use_linked_norms(linked)
                 ids = list(range(n_req))
                 for r in ids:
                     m.add_request(r)
@@ -495,9 +497,11 @@ def model_step_rows(nv, torch, dev, args):
                 dt = statistics.median(times)
                 weight_bytes = 4 * (sum(sizes) - V * D) + 4 * V * D  # layers + final norm, and the classifier (= embedding rows)
                 kv_bytes = int(n_req * L * 2 * (ctx + 3 + steps / 2) * KV * hd * 4)
-                res[f"model_step_tinyllama_b{n_req}"] = {
+                res[f"model_step_tinyllama_b{n_req}" + ("_linked_norms" if linked else "")] = {
                     "workload": f"LlamaModel::forward as one batched decode step, TinyLlama geometry, {n_req} request(s) "
-                                f"at ~{ctx} context tokens, greedy",
+                                f"at ~{ctx} context tokens, greedy"
+                                + ("; nvk_model_use_linked_norms(1): the norms carried between the GEMVs, 6 launches per "
+                                   "layer instead of 8 (opt-in: a few ulp from the separate norm kernels)" if linked else ""),
                     "ref": "include/core/model.hpp:150-247", "bound": "hbm", "steps": steps,
                     "ms_per_step": round(dt * 1e3, 4), "ms_per_step_min": round(min(times) * 1e3, 4),
                     "tokens_per_s": round(n_req / dt, 1),
