@@ -80,3 +80,12 @@ for x in range(8):
         d = (s[sel, 2] - s[sel, 1]) / 100.0
         print(f"    xcd {x}: n {sel.sum():4d}  med {np.median(d):8.2f}  max {d.max():8.2f}   by id // 8 quartiles: "
               + " ".join(f"{np.median(q):7.2f}" for q in np.array_split(d, 4)))
+# how many workgroups are inside their main loop at every 5 us mark (256 CUs: a launch streams at full rate while ~256 are)
+ok = s[:, 2] > 0
+a0, a1 = us(s[ok, 1]), us(s[ok, 2])
+end = float(us(last).max())
+marks = np.arange(0.0, end + 5.0, 5.0)
+print("  workgroups in their main loop at t (us):  " + "  ".join(f"{t:.0f}:{int(((a0 <= t) & (a1 > t)).sum())}" for t in marks))
+busy = float((a1 - a0).sum())
+print(f"  main-loop time summed over workgroups {busy:.0f} us = {busy / 256.0:.1f} us per CU of a {end:.1f} us launch "
+      f"({100.0 * busy / 256.0 / end:.0f} % of the launch's CU-time is spent streaming)")
