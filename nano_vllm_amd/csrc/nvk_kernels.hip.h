@@ -127,7 +127,13 @@ struct DecodeParams
     int            *arrivals;
     // Uniform batches: workgroup i takes item (i % 8) * (n / 8) + i / 8 instead of item i, so that the workgroups of
     // one XCD (ids go round-robin over the 8 XCDs) stream one contiguous eighth of the batch -- see xcd_range_item.
+    // 2 or 4: the XCDs share ranges in pairs or fours (xcd_group_item).
     int             xcd_ranges;
+    // The even XCDs of an MI355X stream 3-6 % slower than the odd ones (profiles/r03_xcd_balance.log), and a workgroup
+    // never changes XCD.  Not 0 (only with xcd_ranges = 2, an even number of full chunks per sequence, where a sequence's
+    // even chunks run on even XCDs and its odd chunks on the odd XCD beside it): every even chunk hands its last
+    // chunk_skew tokens to the odd chunk that follows.
+    int             chunk_skew;
 #ifdef NVK_STAMPS // diagnostic build: sixteen 100 MHz timestamps per workgroup (tools/wg_timeline.py)
     unsigned long long *stamps;
 #endif
@@ -205,6 +211,16 @@ __device__ __forceinline__ int xcd_range_item(int id, int n, int enabled)
         return id;
     const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
     return x * q + min(x, r) + k;
+}
+
+// The same with the XCDs taken g = 2 or 4 at a time (n a multiple of 8): XCDs (g i .. g i + g - 1) own the i-th
+// contiguous g/8 of the items and take turns in it, so XCD x streams every g-th item of its group's range -- with an
+// even number of chunks per sequence and g = 2, the even chunks run on even XCDs and the odd chunks on the odd XCD
+// beside it, which is what DecodeParams::chunk_skew needs.  A bijection of [0, n).
+__device__ __forceinline__ int xcd_group_item(int id, int n, int g)
+{
+    const int x = id & 7, k = id >> 3;
+    return (x / g) * ((n >> 3) * g) + g * k + x % g;
 }
 
 // ---- the plan kernel: context lengths -> work items, longest first ----------
@@ -469,10 +485,11 @@ __device__ __forceinline__ void decode_body(const DecodeParams &p)
     if (p.direct) {
         if (item_i >= p.num_seqs * p.max_chunks)
             return;
-        item_i  = xcd_range_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges);
+        item_i  = p.xcd_ranges > 1 ? xcd_group_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges)
+                                   : xcd_range_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges);
         seq     = item_i / p.max_chunks;
         chunk   = item_i - seq * p.max_chunks;
-        t0      = chunk * p.chunk_tokens;
+        t0      = chunk * p.chunk_tokens - (chunk & 1) * p.chunk_skew;
         ctx_raw = p.ctx_lens ? p.ctx_lens[seq] : p.uniform_ctx; // used only after the q and table loads are on their way
     }
     else {
@@ -522,7 +539,8 @@ __device__ __forceinline__ void decode_body(const DecodeParams &p)
     // one the length is still on its way, so the whole chunk's range is staged (entries past a sequence's end are
     // padding of its row: readable, clamped, never used).
     const int blk0 = token_block(t0, p.bs_magic);
-    const int blk_last = p.direct ? min(token_block(t0 + p.chunk_tokens - 1, p.bs_magic), p.max_blocks - 1)
+    const int chunk_len = p.chunk_tokens + ((chunk & 1) ? p.chunk_skew : -p.chunk_skew); // (direct launches)
+    const int blk_last = p.direct ? min(token_block(t0 + chunk_len - 1, p.bs_magic), p.max_blocks - 1)
                                   : (t1 > t0 ? token_block(t1 - 1, p.bs_magic) : blk0 - 1);
 #ifdef NVK_NO_TABLE_ROWS // A/B build: the decode kernel without the prefill indirection
     const int trow = seq;
@@ -534,7 +552,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams &p)
     if (p.direct) {
         const int ctx = min(max(ctx_raw, 0), p.max_chunks * p.chunk_tokens);
         nch           = (ctx + p.chunk_tokens - 1) / p.chunk_tokens;
-        t1            = min(ctx, t0 + p.chunk_tokens);
+        t1            = min(ctx, t0 + chunk_len);
         if (chunk >= max(nch, 1))
             return; // the sequence ends before this chunk (an empty sequence keeps chunk 0: it zeroes the row)
     }
@@ -768,6 +786,7 @@ __device__ __forceinline__ void decode_body(const DecodeParams &p)
                     *reinterpret_cast<float4 *>(rec + 4 + (j * 16 + r) * 4) = o[h][j];
             }
         }
+        NVK_STAMP(7) // (diagnostic build: this wave's records are in LDS)
         __syncthreads();
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -964,7 +983,8 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
     if (p.direct) {
         if (item_i >= p.num_seqs * p.max_chunks)
             return;
-        item_i  = xcd_range_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges);
+        item_i  = p.xcd_ranges > 1 ? xcd_group_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges)
+                                   : xcd_range_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges);
         seq     = item_i / p.max_chunks;
         chunk   = item_i - seq * p.max_chunks;
         t0      = chunk * p.chunk_tokens;

@@ -61,6 +61,12 @@
 #ifndef NVK_XCD_RANGES
 #define NVK_XCD_RANGES 1 // 1: uniform batches deal each XCD a contiguous eighth of the items (xcd_range_item)
 #endif
+#ifndef NVK_XCD_SKEW_PERMILLE
+#define NVK_XCD_SKEW_PERMILLE 40 // thousandths of a chunk that an even XCD's chunk hands to the odd XCD's behind it ...
+#endif
+#ifndef NVK_XCD_SKEW_MIN_CHUNK
+#define NVK_XCD_SKEW_MIN_CHUNK 1024 // ... in uniform batches cut into chunks of at least this many tokens (enqueue_planned)
+#endif
 #ifndef NVK_POOL_SKEW_BYTES
 #define NVK_POOL_SKEW_BYTES 0 // bytes of padding behind every slab of the one-allocation layout (a multiple of 256)
 #endif
@@ -430,7 +436,9 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     plan->wide = NVK_WIDE_STEPS && !plan->free_forced && !plan->mfma && plan->kpw == 1 && plan->vpl == 2 && plan->full && plan->qpk <= 4
                  && plan->kv_groups == 1 && plan->parts == 1 && plan->chunk_tokens >= NVK_WIDE_MIN_CHUNK
                  && plan->chunk_tokens % 16 == 0;
-    plan->merge_off    = (plan->chunk_tokens / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
+    // (a skewed launch -- DecodeParams::chunk_skew -- stages up to a 16th more of the table than the chunk's own slice)
+    const int skew_room = plan->parts == 1 && !plan->mfma ? plan->chunk_tokens / 16 : 0;
+    plan->merge_off    = ((plan->chunk_tokens + skew_room) / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
     plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int) + merge_bytes;
     if (plan->lds_bytes > (size_t)kLdsPerLaunch) // (cannot happen: the chunk was bounded for it above)
         return nvk::fail(NVK_ERR_INVALID_ARG, "decode: the launch needs %zu bytes of LDS, more than %d", plan->lds_bytes,
@@ -729,10 +737,31 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     // (only where a workgroup's waves are the kv-heads of whole token rows: with token-split waves -- a head-sharded
     // rank's 512-B rows -- the same dealing measured 0.61-0.76 against 0.81, profiles/r02_sweep_item_order.log)
     p.xcd_ranges = (NVK_XCD_RANGES && plan->direct && !plan->ctx_lens_dev && kv_mul == sh.qpk && sh.parts == 1) ? 1 : 0;
+    // Long chunks (the wide kernel), every chunk full, an even number of them per sequence, whole rounds of the 8 XCDs:
+    // the XCDs take their ranges in pairs, even chunks on even XCDs, and every even chunk hands a few tokens (whole
+    // steps) to the odd chunk behind it -- the even XCDs of an MI355X stream 3-6 % slower than the odd ones and the
+    // launch ends with the slowest.  Measured: config 4 0.874-0.880 -> 0.895-0.897 of the HBM peak; 512-token chunks
+    // (config 2) lose 1 % to the paired dealing and gain nothing from the skew (profiles/r03_xcd_balance.log).
+    int skew_permille = NVK_XCD_SKEW_PERMILLE, skew_min_chunk = NVK_XCD_SKEW_MIN_CHUNK;
 #ifdef NVK_XCD_RANGES_ENV // A/B build
     if (getenv("NVK_XCD_RANGES_OFF"))
         p.xcd_ranges = 0;
+    if (const char *e = getenv("NVK_XCD_SKEW"))
+        skew_permille = atoi(e);
+    if (const char *e = getenv("NVK_XCD_SKEW_MIN_CHUNK"))
+        skew_min_chunk = atoi(e);
+    if (const char *e = getenv("NVK_XCD_GROUP")) // the dealing alone: XCDs in pairs or fours
+        if (p.xcd_ranges && (atoi(e) == 2 || atoi(e) == 4) && ((long long)plan->num_seqs * sh.max_chunks) % 8 == 0)
+            p.xcd_ranges = atoi(e);
 #endif
+    p.chunk_skew = 0;
+    if (p.xcd_ranges && skew_permille > 0 && !sh.mfma && sh.chunk_tokens >= skew_min_chunk && sh.max_chunks % 2 == 0
+        && plan->uniform_ctx == sh.max_chunks * sh.chunk_tokens && ((long long)plan->num_seqs * sh.max_chunks) % 8 == 0) {
+        const int step = sh.wide ? 16 : 8, room = sh.chunk_tokens / 16; // (make_shape left the table slice that much room)
+        p.chunk_skew   = std::min((int)((long long)sh.chunk_tokens * skew_permille / 1000 + step / 2) / step * step, room / step * step);
+        if (p.chunk_skew > 0)
+            p.xcd_ranges = 2;
+    }
 #ifdef NVK_STAMPS
     p.stamps = g_debug_stamps;
 #endif

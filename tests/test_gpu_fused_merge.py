@@ -189,3 +189,36 @@ def test_uniform_batches_of_any_size_cover_every_item(n):
             uniform = decode_dev(pool, work, q, work.block_tables, ctx, mode | nv.UNIFORM, chunk, max_ctx=T, ctx_dev=None)
             assert np.isfinite(uniform).all(), f"n={n} mode 0x{mode:x}: an item was never computed"
             assert same_bits(planned, uniform), f"n={n} mode 0x{mode:x}"
+
+
+@pytest.mark.parametrize("bs,n,T,chunk", [(16, 4, 4096, 1024), (24, 8, 2048, 1024), (16, 2, 8192, 2048)])
+def test_long_uniform_chunks_skewed_between_xcd_pairs(bs, n, T, chunk):
+    """Uniform batches cut into long full chunks (>= 1024 tokens, an even number per sequence, whole rounds of the 8
+    XCDs) are dealt to the XCDs in pairs and every even chunk hands 4 % of its tokens to the odd chunk behind it
+    (DecodeParams::chunk_skew: the even XCDs stream slower).  Chunk boundaries that no longer sit on multiples of
+    the chunk size -- nor, at block size 24, on block boundaries: both combines give the same bits, every row matches
+    the checker, and the bits differ from the planned launch's (whose chunks are all equal), so the skew was on."""
+    g = wl.Geometry(32, 8, 128, bs)
+    ctx = np.full(n, T, np.int32)
+    work = wl.fragmented_workload(f"skew{bs}x{n}x{T}", ctx, g, perm_seed=bs + n)
+    q = work.q()
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(n)))
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, bs, g.n_kv_heads, n_threads=4)
+    with nv.PagedKVPool(1, work.num_blocks, bs, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        planned = decode_dev(pool, work, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
+        fused = decode_dev(pool, work, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_IN_KERNEL | nv.UNIFORM, chunk,
+                           max_ctx=T, ctx_dev=None)
+        apart = decode_dev(pool, work, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_SEPARATE | nv.UNIFORM, chunk,
+                           max_ctx=T, ctx_dev=None)
+        assert np.isfinite(fused).all()
+        assert same_bits(fused, apart)
+        assert_close(fused, want, f"skewed chunks bs={bs} {n}x{T}")
+        assert_close(planned, want, f"planned bs={bs} {n}x{T}")
+        assert not same_bits(fused, planned), "equal chunks: the skew was not applied"
+        # one token short of full chunks: no skew, the planned launch's bits again
+        short = np.full(n, T - 1, np.int32)
+        p2 = decode_dev(pool, work, q, work.block_tables, short, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
+        u2 = decode_dev(pool, work, q, work.block_tables, short, nv.SPLIT_K | nv.MERGE_IN_KERNEL | nv.UNIFORM, chunk,
+                        max_ctx=T - 1, ctx_dev=None)
+        assert same_bits(p2, u2)

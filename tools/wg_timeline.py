@@ -55,6 +55,10 @@ dist("main loop end", us(s[ok, 2]))
 ok = s[:, 4] > 0
 if ok.any():
     dist("store+drain+barrier (4 - 2)", (s[ok, 4] - s[ok, 2]) / 100.0)
+    ok7 = ok & (s[:, 7] > 0)
+    if ok7.any():  # token-split shapes: wave 0's own join (shuffles, records to LDS), then the parts' meeting and the stores
+        dist("  wave 0's slots joined, records in LDS (7 - 2)", (s[ok7, 7] - s[ok7, 2]) / 100.0)
+        dist("  parts met, merged, partial stored (3 - 7)", (s[ok7, 3] - s[ok7, 7]) / 100.0)
     ok3 = ok & (s[:, 3] > 0)
     if ok3.any():
         dist("  wave join + partial stored (3 - 2)", (s[ok3, 3] - s[ok3, 2]) / 100.0)
