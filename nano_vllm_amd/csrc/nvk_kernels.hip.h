@@ -231,6 +231,19 @@ __device__ __forceinline__ int xcd_group_item(int id, int n, int g)
 // reference does first of all (attention.hpp:98).  Which of two equally long
 // partial chunks comes first is arbitrary and does not affect any result: every
 // item is computed independently and merged per sequence in chunk order.
+// chunk_skew (long chunks only, see DecodeParams::chunk_skew): item = workgroup id here, so the items at even
+// positions run on even XCDs -- the slower ones.  Where two neighbours in the list (2j, 2j + 1) are consecutive full
+// chunks of one sequence, the first hands its last chunk_skew tokens to the second.
+__host__ __device__ __forceinline__ int2 skewed_chunk(int pos, int c, int nfull, int chunk_tokens, int chunk_skew)
+{
+    int2 t = make_int2(c * chunk_tokens, (c + 1) * chunk_tokens);
+    if (!(pos & 1) && c + 1 < nfull)
+        t.y -= chunk_skew;
+    else if ((pos & 1) && c >= 1)
+        t.x -= chunk_skew;
+    return t;
+}
+
 // Inclusive scan of one int per thread over the whole workgroup (kPlanThreads = 16 waves):
 // shuffle scan inside each wave, wave totals through LDS, two barriers in all.
 __device__ __forceinline__ int block_inclusive_scan(int v, int *s_wave_totals)
@@ -255,7 +268,7 @@ __device__ __forceinline__ int block_inclusive_scan(int v, int *s_wave_totals)
 
 __global__ void __launch_bounds__(kPlanThreads)
     nvk_plan_kernel(const int *__restrict__ ctx_lens, int num_seqs, int chunk_tokens, int max_chunks,
-                    WorkItem *__restrict__ items, int *__restrict__ n_items, int *__restrict__ seq_chunks)
+                    WorkItem *__restrict__ items, int *__restrict__ n_items, int *__restrict__ seq_chunks, int chunk_skew)
 {
     static_assert(kPlanBuckets == kPlanThreads, "one bucket per thread in the bucket scan");
     __shared__ int s_totals[kPlanThreads / 64];
@@ -281,8 +294,10 @@ __global__ void __launch_bounds__(kPlanThreads)
         const int nch   = nfull + (rem > 0 ? 1 : 0);
         const int incl  = block_inclusive_scan(nfull, s_totals);
         const int first = n_full + incl - nfull;
-        for (int c = 0; c < nfull; c++)
-            items[first + c] = WorkItem{s, c | (nch << 16), c * chunk_tokens, (c + 1) * chunk_tokens};
+        for (int c = 0; c < nfull; c++) {
+            int2 t = skewed_chunk(first + c, c, nfull, chunk_tokens, chunk_skew);
+            items[first + c] = WorkItem{s, c | (nch << 16), t.x, t.y};
+        }
         if (s < num_seqs) {
             seq_chunks[s] = nch;
             if (rem > 0 || ctx == 0)

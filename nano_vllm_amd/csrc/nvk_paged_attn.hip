@@ -294,6 +294,7 @@ struct LaunchShape
     int waves        = 1; // kv-heads per workgroup (waves along the kv axis)
     int parts        = 1; // token-split factor: waves * parts waves per workgroup
     int merge_off    = 0; // int offset of the token-split merge area in LDS
+    int chunk_skew   = 0; // tokens an even XCD's full chunk hands to the odd XCD's behind it (long chunks; enqueue_planned)
     int kv_groups    = 1;
     int qpk          = 1; // q-heads per wave
     int vpl          = 1;
@@ -436,8 +437,27 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     plan->wide = NVK_WIDE_STEPS && !plan->free_forced && !plan->mfma && plan->kpw == 1 && plan->vpl == 2 && plan->full && plan->qpk <= 4
                  && plan->kv_groups == 1 && plan->parts == 1 && plan->chunk_tokens >= NVK_WIDE_MIN_CHUNK
                  && plan->chunk_tokens % 16 == 0;
-    // (a skewed launch -- DecodeParams::chunk_skew -- stages up to a 16th more of the table than the chunk's own slice)
-    const int skew_room = plan->parts == 1 && !plan->mfma ? plan->chunk_tokens / 16 : 0;
+    // Long chunks, one workgroup per item whose id is the item's place in the list (so the place's parity is the XCD's):
+    // every even XCD's full chunk hands a few tokens (whole steps) to the odd XCD's chunk behind it -- the even XCDs of
+    // an MI355X stream 3-6 % slower than the odd ones and a launch ends with the slowest.  Measured: config 4 0.86-0.87
+    // -> 0.88-0.89 of the HBM peak; 512-token chunks gain nothing (profiles/r03_xcd_balance.log).  The table slice
+    // in LDS gets room for the longer chunks.
+    plan->chunk_skew = 0;
+    {
+        int permille = NVK_XCD_SKEW_PERMILLE, min_chunk = NVK_XCD_SKEW_MIN_CHUNK;
+#ifdef NVK_XCD_RANGES_ENV // A/B build
+        if (const char *e = getenv("NVK_XCD_SKEW"))
+            permille = atoi(e);
+        if (const char *e = getenv("NVK_XCD_SKEW_MIN_CHUNK"))
+            min_chunk = atoi(e);
+#endif
+        if (permille > 0 && plan->parts == 1 && !plan->mfma && plan->kv_groups == 1 && plan->qpk == kv_mul
+            && plan->chunk_tokens >= min_chunk) {
+            const int step = plan->wide ? 16 : 8, room = plan->chunk_tokens / 16;
+            plan->chunk_skew = std::min((int)((long long)plan->chunk_tokens * permille / 1000 + step / 2) / step * step, room / step * step);
+        }
+    }
+    const int skew_room = plan->chunk_skew;
     plan->merge_off    = ((plan->chunk_tokens + skew_room) / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
     plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int) + merge_bytes;
     if (plan->lds_bytes > (size_t)kLdsPerLaunch) // (cannot happen: the chunk was bounded for it above)
@@ -629,7 +649,7 @@ int plan_launch(nvk_plan *plan, const int *ctx_dev, hipStream_t stream)
     if (!plan->direct && plan->num_seqs > 0) {
         hipLaunchKernelGGL(nvk::nvk_plan_kernel, dim3(1), dim3(nvk::kPlanThreads), 0, stream, ctx_dev, plan->num_seqs,
                            plan->shape.chunk_tokens, plan->shape.max_chunks, plan->items, plan->counters,
-                           plan->counters + 1);
+                           plan->counters + 1, plan->shape.chunk_skew);
         HIP_TRY(hipGetLastError());
     }
     plan->built = true;
@@ -737,30 +757,21 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     // (only where a workgroup's waves are the kv-heads of whole token rows: with token-split waves -- a head-sharded
     // rank's 512-B rows -- the same dealing measured 0.61-0.76 against 0.81, profiles/r02_sweep_item_order.log)
     p.xcd_ranges = (NVK_XCD_RANGES && plan->direct && !plan->ctx_lens_dev && kv_mul == sh.qpk && sh.parts == 1) ? 1 : 0;
-    // Long chunks (the wide kernel), every chunk full, an even number of them per sequence, whole rounds of the 8 XCDs:
-    // the XCDs take their ranges in pairs, even chunks on even XCDs, and every even chunk hands a few tokens (whole
-    // steps) to the odd chunk behind it -- the even XCDs of an MI355X stream 3-6 % slower than the odd ones and the
-    // launch ends with the slowest.  Measured: config 4 0.874-0.880 -> 0.895-0.897 of the HBM peak; 512-token chunks
-    // (config 2) lose 1 % to the paired dealing and gain nothing from the skew (profiles/r03_xcd_balance.log).
-    int skew_permille = NVK_XCD_SKEW_PERMILLE, skew_min_chunk = NVK_XCD_SKEW_MIN_CHUNK;
 #ifdef NVK_XCD_RANGES_ENV // A/B build
     if (getenv("NVK_XCD_RANGES_OFF"))
         p.xcd_ranges = 0;
-    if (const char *e = getenv("NVK_XCD_SKEW"))
-        skew_permille = atoi(e);
-    if (const char *e = getenv("NVK_XCD_SKEW_MIN_CHUNK"))
-        skew_min_chunk = atoi(e);
     if (const char *e = getenv("NVK_XCD_GROUP")) // the dealing alone: XCDs in pairs or fours
         if (p.xcd_ranges && (atoi(e) == 2 || atoi(e) == 4) && ((long long)plan->num_seqs * sh.max_chunks) % 8 == 0)
             p.xcd_ranges = atoi(e);
 #endif
+    // LaunchShape::chunk_skew without a plan: every chunk full, an even number of them per sequence, whole rounds of the
+    // 8 XCDs -- the XCDs take their ranges in pairs, even chunks on even XCDs (with a plan the work list carries the
+    // chunks' bounds: nvk::skewed_chunk)
     p.chunk_skew = 0;
-    if (p.xcd_ranges && skew_permille > 0 && !sh.mfma && sh.chunk_tokens >= skew_min_chunk && sh.max_chunks % 2 == 0
-        && plan->uniform_ctx == sh.max_chunks * sh.chunk_tokens && ((long long)plan->num_seqs * sh.max_chunks) % 8 == 0) {
-        const int step = sh.wide ? 16 : 8, room = sh.chunk_tokens / 16; // (make_shape left the table slice that much room)
-        p.chunk_skew   = std::min((int)((long long)sh.chunk_tokens * skew_permille / 1000 + step / 2) / step * step, room / step * step);
-        if (p.chunk_skew > 0)
-            p.xcd_ranges = 2;
+    if (p.xcd_ranges && sh.chunk_skew > 0 && sh.max_chunks % 2 == 0 && plan->uniform_ctx == sh.max_chunks * sh.chunk_tokens
+        && ((long long)plan->num_seqs * sh.max_chunks) % 8 == 0) {
+        p.chunk_skew = sh.chunk_skew;
+        p.xcd_ranges = 2;
     }
 #ifdef NVK_STAMPS
     p.stamps = g_debug_stamps;
@@ -1957,8 +1968,10 @@ int nvk_decode(nvk_pool *pool, int layer, int num_seqs, int n_heads, const float
             const int ctx = std::min(ctx_lens[s2], sh.max_chunks * ct), nfull = ctx / ct, rem = ctx - nfull * ct;
             const int nch = nfull + (rem > 0 ? 1 : 0);
             cnt[1 + s2]   = nch;
-            for (int c = 0; c < nfull; c++)
-                items[n++] = nvk::WorkItem{s2, c | (nch << 16), c * ct, (c + 1) * ct};
+            for (int c = 0; c < nfull; c++, n++) {
+                const int2 t = nvk::skewed_chunk(n, c, nfull, ct, sh.chunk_skew);
+                items[n]     = nvk::WorkItem{s2, c | (nch << 16), t.x, t.y};
+            }
         }
         const int first_partial = n;
         for (int s2 = 0; s2 < num_seqs; s2++) {

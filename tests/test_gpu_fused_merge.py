@@ -192,12 +192,14 @@ def test_uniform_batches_of_any_size_cover_every_item(n):
 
 
 @pytest.mark.parametrize("bs,n,T,chunk", [(16, 4, 4096, 1024), (24, 8, 2048, 1024), (16, 2, 8192, 2048)])
-def test_long_uniform_chunks_skewed_between_xcd_pairs(bs, n, T, chunk):
-    """Uniform batches cut into long full chunks (>= 1024 tokens, an even number per sequence, whole rounds of the 8
-    XCDs) are dealt to the XCDs in pairs and every even chunk hands 4 % of its tokens to the odd chunk behind it
-    (DecodeParams::chunk_skew: the even XCDs stream slower).  Chunk boundaries that no longer sit on multiples of
-    the chunk size -- nor, at block size 24, on block boundaries: both combines give the same bits, every row matches
-    the checker, and the bits differ from the planned launch's (whose chunks are all equal), so the skew was on."""
+def test_long_chunks_skewed_between_even_and_odd_xcds(bs, n, T, chunk):
+    """Sequences cut into long chunks (>= 1024 tokens): every full chunk that runs on an even XCD hands 4 % of its
+    tokens to the chunk behind it on the odd XCD beside it (LaunchShape::chunk_skew: the even XCDs stream slower).
+    With a plan the work list carries the bounds (nvk::skewed_chunk, by the item's place in the list); without one
+    (uniform batch, an even number of full chunks, whole rounds of the XCDs) the kernel works them out of its id.
+    Chunk bounds that no longer sit on multiples of the chunk size -- nor, at block size 24, on block boundaries:
+    both combines give the same bits, every row matches the checker, and -- the same bounds either way here -- the
+    planned and the plan-free launch give the same bits.  One token short of full chunks only the plan skews."""
     g = wl.Geometry(32, 8, 128, bs)
     ctx = np.full(n, T, np.int32)
     work = wl.fragmented_workload(f"skew{bs}x{n}x{T}", ctx, g, perm_seed=bs + n)
@@ -211,14 +213,20 @@ def test_long_uniform_chunks_skewed_between_xcd_pairs(bs, n, T, chunk):
                            max_ctx=T, ctx_dev=None)
         apart = decode_dev(pool, work, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_SEPARATE | nv.UNIFORM, chunk,
                            max_ctx=T, ctx_dev=None)
+        host = nv.decode(pool, 0, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
         assert np.isfinite(fused).all()
         assert same_bits(fused, apart)
+        assert same_bits(fused, planned)
+        assert same_bits(fused, host)
         assert_close(fused, want, f"skewed chunks bs={bs} {n}x{T}")
-        assert_close(planned, want, f"planned bs={bs} {n}x{T}")
-        assert not same_bits(fused, planned), "equal chunks: the skew was not applied"
-        # one token short of full chunks: no skew, the planned launch's bits again
-        short = np.full(n, T - 1, np.int32)
-        p2 = decode_dev(pool, work, q, work.block_tables, short, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
-        u2 = decode_dev(pool, work, q, work.block_tables, short, nv.SPLIT_K | nv.MERGE_IN_KERNEL | nv.UNIFORM, chunk,
-                        max_ctx=T - 1, ctx_dev=None)
-        assert same_bits(p2, u2)
+        # ragged: the plan skews the pairs of full chunks it finds, the last (partial) chunks stay as they are
+        ragged = np.array([T - 1 - 1000 * (i % 3) for i in range(n)], np.int32)
+        k2, v2, t2, c2 = wl.host_blocks_for(work, list(range(n)))
+        want2 = ol.oracle_decode_batch(q, k2, v2, t2, ragged, bs, g.n_kv_heads, n_threads=4)
+        p2 = decode_dev(pool, work, q, work.block_tables, ragged, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
+        s2 = decode_dev(pool, work, q, work.block_tables, ragged, nv.SPLIT_K | nv.MERGE_SEPARATE, chunk)
+        d2 = decode_dev(pool, work, q, work.block_tables, ragged, nv.SPLIT_K | nv.NO_PLAN, chunk)
+        h2 = nv.decode(pool, 0, q, work.block_tables, ragged, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
+        assert same_bits(p2, s2) and same_bits(p2, h2)
+        assert_close(p2, want2, f"ragged, planned bs={bs}")
+        assert_close(d2, want2, f"ragged, no plan bs={bs}")
