@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 
 #include "nvk_device_scope.h"
@@ -81,12 +82,21 @@
 #ifndef NVK_SKINNY16_WIDE
 #define NVK_SKINNY16_WIDE 1 // 17-64 rows over few columns: 16 x 16 tiles, one workgroup per row tile (0: 32 x 32 tiles)
 #endif
+#ifndef NVK_NT_SPLIT_MIN_ROWS
+#define NVK_NT_SPLIT_MIN_ROWS 97 // from here a plain product whose 64 x 64 tiles leave CUs idle is cut along k (nvk_gemm_nt_kernel<.., SPLIT>)
+#endif
+#ifndef NVK_NT_SPLIT_MIN_K
+#define NVK_NT_SPLIT_MIN_K 256 // ... into slices of at least this many contraction steps
+#endif
 #ifndef NVK_SKINNY_MAX_ROWS
 #define NVK_SKINNY_MAX_ROWS 96 // up to here the weight-streaming MFMA kernel (32-row tiles), above it the tiled one
 #endif
 
 static_assert(NVK_GEMV_MAX_ROWS >= 0 && NVK_GEMV_MAX_ROWS <= 2, "nvk_gemv_kernel is instantiated for one and two rows");
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "nvk_linear.hip: the split-K tile combine is written for gfx950 (sc1 write-through stores); build with --offload-arch=gfx950"
+#endif
 namespace nvk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -114,6 +124,12 @@ struct LinearParams
     LinearSeg    seg[3];
     int          nseg, n_tiles, m_tiles;
     int          cw; // nvk_gemm_skinny16_kernel: output columns per workgroup (a multiple of 4)
+    // nvk_gemm_nt_kernel<.., SPLIT>: the contraction cut into `ksplit` slices of `kslice` (a multiple of BK), one
+    // workgroup per (tile, slice); partial tiles in `part` [tile][slice][BM x BN], arrivals per tile in `arrive` (zero
+    // between launches: the workgroup that completes a tile sums its slices in slice order and zeroes the counter)
+    int          ksplit, kslice;
+    float       *part;
+    int         *arrive;
     RopeAppendTarget rope; // nvk_gemv_kernel<.., ROPE>: where the q / k / v epilogue writes
     NormLink         link; // nvk_gemv_kernel<.., SCALE / RESID>: the norm carried from one GEMV to the next
 };
@@ -222,18 +238,31 @@ __global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ o
 // lane (j, half) of MFMA e supplies element k = 8c + 4*half + e of its row.
 // Tile ids are dealt so that the row tiles of one column tile run on one XCD at about the same time
 // (ids go round-robin over the 8 XCDs): the weight tile is then read from HBM once and met in that L2.
-template <int BM, int BN, int BK> __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams p)
+// SPLIT (few rows x few columns: the tiles alone leave most CUs idle -- 64 rows x 2048 columns are 32 of them): the
+// contraction is cut into p.ksplit slices, a workgroup per (tile, slice).  Every workgroup stores its partial tile
+// write-through (sc1), the one whose arrival completes the tile (agent-scope counter, the protocol of the decode
+// kernel's split-K combine, nvk_kernels.hip.h) adds the slices IN SLICE ORDER -- the same bits whoever comes last --
+// and stores the tile.  Nobody waits for anybody.
+template <int BM, int BN, int BK, bool SPLIT = false>
+__global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams p)
 {
     constexpr int TA = BM / 64, TB = BN / 64; // 32 x 32 MFMA tiles per wave along the rows / the columns
     constexpr int kGemmBK = BK, kGemmLds = BK + 4, KV = BK / 32; // KV: float4 per thread per tile row pass
     extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [2][BM + BN][kGemmLds]
 
+    int bid = blockIdx.x, slice = 0;
+    if (SPLIT) { // slices outermost: the workgroups of one slice are dealt as an unsplit launch's
+        const int per = gridDim.x / p.ksplit;
+        slice         = bid / per;
+        bid -= slice * per;
+    }
     const int span = 8 * p.m_tiles;
-    const int rem  = blockIdx.x % span;
-    const int nt   = blockIdx.x / span * 8 + rem % 8;
+    const int rem  = bid % span;
+    const int nt   = bid / span * 8 + rem % 8;
     const int mt   = rem / 8;
     if (nt >= p.n_tiles)
-        return;
+        return; // (padding of the grid: no slice of such a tile exists, nobody counts on it)
+    const int kbeg = SPLIT ? slice * p.kslice : 0, kend = SPLIT ? min(p.k, kbeg + p.kslice) : p.k;
     const LinearSeg sg = segment_of(p, nt);
     const int       n0 = (nt - sg.tile0) * BN, m0 = mt * BM;
 
@@ -259,7 +288,7 @@ template <int BM, int BN, int BK> __global__ void __launch_bounds__(256, 2) nvk_
     auto fetch = [&](Regs &r, int k0) {
 #pragma unroll
         for (int u = 0; u < KV; u++) {
-            const bool inside = k0 + 32 * u + lc < p.k; // k % 4 == 0: a float4 is wholly inside or outside
+            const bool inside = k0 + 32 * u + lc < kend; // k % 4 == 0: a float4 is wholly inside or outside
 #pragma unroll
             for (int i = 0; i < BM / 32; i++)
                 r.a[i][u] = inside ? *reinterpret_cast<const float4 *>(arow[i] + k0 + 32 * u)
@@ -324,10 +353,10 @@ template <int BM, int BN, int BK> __global__ void __launch_bounds__(256, 2) nvk_
         }
     };
 
-    const int nk  = (p.k + kGemmBK - 1) / kGemmBK;
+    const int nk  = (kend - kbeg + kGemmBK - 1) / kGemmBK;
     // the walk over k starts at a tile that depends on the column tile (see nvk_gemm_skinny_kernel: HBM channels)
     const int rot = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
-    auto      k_at = [&](int kt) { return ((kt + rot) % nk) * kGemmBK; };
+    auto      k_at = [&](int kt) { return kbeg + ((kt + rot) % nk) * kGemmBK; };
     // tile kt sits in LDS buffer kt & 1; at the top of step kt the registers r[(kt + 1) & 1] hold (or await)
     // tile kt + 1 and r[kt & 1] is free for tile kt + 2
     fetch(r0, k_at(0));
@@ -352,6 +381,63 @@ template <int BM, int BN, int BK> __global__ void __launch_bounds__(256, 2) nvk_
         }
     }
 
+    if (SPLIT) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int        kSc1  = 16; // aux bit 4 of the buffer instructions on gfx950: write-through
+        constexpr int        kTile = BM * BN;
+        const int            tile  = mt * p.n_tiles + nt;
+        float               *mine  = p.part + ((int64_t)tile * p.ksplit + slice) * kTile;
+        // a thread's accumulators as float4s, [float4 index][thread]: coalesced both ways
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, kTile * 4, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < TA; a++)
+#pragma unroll
+            for (int b = 0; b < TB; b++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 v = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                           ((((a * TB + b) * 4 + q) * 256) + tid) * 16, 0, kSc1);
+                }
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int      *cnt  = p.arrive + tile;
+            const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == p.ksplit - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // zero again for the next launch
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last)
+            return;
+        const float *all = p.part + (int64_t)tile * p.ksplit * kTile;
+#pragma unroll
+        for (int a = 0; a < TA; a++)
+#pragma unroll
+            for (int b = 0; b < TB; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc[a][b][r] = 0.f;
+        for (int sl = 0; sl < p.ksplit; sl++) {
+            const float4 *src = reinterpret_cast<const float4 *>(all + (int64_t)sl * kTile) + tid;
+#pragma unroll
+            for (int a = 0; a < TA; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 v = src[((a * TB + b) * 4 + q) * 256];
+                        acc[a][b][4 * q] += v.x, acc[a][b][4 * q + 1] += v.y, acc[a][b][4 * q + 2] += v.z,
+                            acc[a][b][4 * q + 3] += v.w;
+                    }
+        }
+    }
     // D[row][col]: col = lane & 31, register r holds row (r & 3) + 8 * (r >> 2) + 4 * half
 #pragma unroll
     for (int a = 0; a < TA; a++)
@@ -1099,6 +1185,77 @@ int opt_in_lds(const void *kernel, size_t lds_bytes, int device)
     return NVK_OK;
 }
 
+// Where the split-K launches of one stream keep their partial tiles and arrival counters: one buffer per (device,
+// stream), grown on demand and kept -- launches on one stream run one after the other, so they can share it; two
+// streams never do.  Allocating is not possible while the stream is being captured: the caller then takes the unsplit
+// path (an engine's first step of a shape runs uncaptured, which is when this grows).
+struct SplitWorkspace
+{
+    float *part    = nullptr;
+    int   *arrive  = nullptr;
+    size_t floats  = 0, counters = 0;
+};
+std::mutex g_split_mutex;
+struct SplitKey
+{
+    int         device;
+    hipStream_t stream;
+    bool        operator<(const SplitKey &o) const { return device != o.device ? device < o.device : stream < o.stream; }
+};
+std::map<SplitKey, SplitWorkspace> g_split_ws;
+
+// returns false when the buffers are too small and cannot be grown now (stream capture in progress, or out of memory)
+bool split_workspace(int device, hipStream_t st, size_t floats, size_t counters, SplitWorkspace *out)
+{
+    std::lock_guard<std::mutex> lock(g_split_mutex);
+    SplitWorkspace &w = g_split_ws[SplitKey{device, st}];
+    if (w.floats < floats || w.counters < counters) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return false;
+        }
+        // whatever ran on this stream with the old buffers is done before they go
+        if (hipStreamSynchronize(st) != hipSuccess)
+            return false;
+        const size_t nf = std::max(floats, w.floats * 2), nc = std::max<size_t>(std::max(counters, w.counters * 2), 1024);
+        float       *pf = nullptr;
+        int         *pc = nullptr;
+        if (hipMalloc(&pf, nf * sizeof(float)) != hipSuccess || hipMalloc(&pc, nc * sizeof(int)) != hipSuccess
+            || hipMemset(pc, 0, nc * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            if (pf)
+                (void)hipFree(pf);
+            if (pc)
+                (void)hipFree(pc);
+            return false;
+        }
+        if (w.part)
+            (void)hipFree(w.part);
+        if (w.arrive)
+            (void)hipFree(w.arrive);
+        w.part = pf, w.arrive = pc, w.floats = nf, w.counters = nc;
+    }
+    *out = w;
+    return true;
+}
+
+// Slices of the contraction for `tiles` 64 x 64 output tiles on `cus` CUs (two workgroups fit a CU): as many as fill
+// the chip about twice, each at least NVK_NT_SPLIT_MIN_K long and a whole number of 64-steps; 1 = not worth cutting.
+int split_slices(long long tiles, int k, int cus, int *kslice)
+{
+    *kslice = k;
+    if (tiles <= 0 || tiles >= cus)
+        return 1;
+    int want = (int)std::min<long long>(16, 2LL * cus / tiles); // (no more workgroups than are resident at once)
+    want     = std::min(want, std::max(1, k / NVK_NT_SPLIT_MIN_K));
+    if (want <= 1)
+        return 1;
+    const int steps = (k + 63) / 64, per = (steps + want - 1) / want;
+    *kslice         = per * 64;
+    return (steps + per - 1) / per; // (every slice has at least one step)
+}
+
 // 16 x 16 tiles in the weight-streaming MFMA kernel: always up to 16 rows; with more rows (several row tiles per
 // column tile, the weights' further readings L2 hits) while 32-column tiles would leave CUs idle -- measured
 // (profiles/r01_qkv_projection.log): 2048 columns x 32 rows 14.6 -> 7.5 us, 5632 -> 2048 at 32 / 64 rows
@@ -1160,15 +1317,38 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     for (int s = 0; s < nseg; s++)
         if ((long long)n[s] * in_dim > 0x7fffffffLL)
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: a %d x %d weight exceeds 2^31 floats", who, n[s], in_dim);
-    nvk::LinearParams p;
-    p.a = in, p.m = batch, p.k = in_dim, p.lda = in_dim;
     long long cols = 0;
     for (int s = 0; s < nseg; s++)
         cols += n[s];
     // (a norm link exists only in the GEMV: two linked rows stay there at any width)
     const bool gemv   = batch <= NVK_GEMV_MAX_ROWS && (batch < 2 || cols <= NVK_GEMV2_MAX_COLS || link);
-    const bool skinny = batch <= NVK_SKINNY_MAX_ROWS;
     const int  cus = cu_count_of(device);
+    // a plain product of more rows than the weight-streaming kernel takes whose 64 x 64 tiles would leave CUs idle: the
+    // tiled kernel with the contraction cut -- 128 rows of 5632 -> 2048: 118.7 -> 33.9 us; at 33-96 rows it is within 10 %
+    // of the weight-streaming kernel either way and stays off
+    // (measured against the weight-streaming kernel and the unsplit tiles: profiles/r03_nt_splitk.log)
+    int       split = 1, kslice = in_dim;
+    long long t64   = 0;
+    for (int s = 0; s < nseg; s++)
+        t64 += (n[s] + 63) / 64;
+    t64 *= (batch + 63) / 64;
+    int split_min_rows = NVK_NT_SPLIT_MIN_ROWS;
+#ifdef NVK_LINEAR_ENV // A/B build
+    if (const char *e = getenv("NVK_NT_SPLIT_MIN_ROWS"))
+        split_min_rows = atoi(e);
+#endif
+    nvk::LinearParams p;
+    p.ksplit = 1, p.kslice = in_dim, p.part = nullptr, p.arrive = nullptr;
+    if (!glu && !rope && !link && batch >= split_min_rows && batch > NVK_GEMV_MAX_ROWS && NVK_GEMM_FORCE_TILE != 128) {
+        split = split_slices(t64, in_dim, cus, &kslice);
+        SplitWorkspace ws;
+        if (split > 1 && split_workspace(device, st, (size_t)t64 * split * 64 * 64, (size_t)t64, &ws))
+            p.ksplit = split, p.kslice = kslice, p.part = ws.part, p.arrive = ws.arrive;
+        else
+            split = 1;
+    }
+    const bool skinny = batch <= NVK_SKINNY_MAX_ROWS && split == 1;
+    p.a = in, p.m = batch, p.k = in_dim, p.lda = in_dim;
     const bool t16 = tile16(batch, n, nseg, cus);
     // fused epilogues beyond the GEMV: the norm link in the 16 x 16 tile kernel up to 16 rows; RoPE + append wherever the
     // weight-streaming kernel gives every row tile a workgroup of its own; SwiGLU only in the GEMV
@@ -1208,7 +1388,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         // measured (profiles/r01_qkv_projection.log): two 128 x 128 workgroups fit a CU, and a launch that is not
         // at least three full rounds of them loses more to the ragged last round than 64 x 64 tiles lose to their
         // four times higher LDS and L2 traffic per flop
-        if (NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
+        if (split > 1 || NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
             bm = bn = 64;
     }
     else
@@ -1362,12 +1542,18 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     }
     else {
         p.m_tiles = (batch + bm - 1) / bm;
-        const long long wgs = (tiles + 7) / 8 * 8 * p.m_tiles;
+        const long long wgs = (tiles + 7) / 8 * 8 * p.m_tiles * split;
         if (wgs > 0x7fffffffLL)
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
-        const int    bk  = bm == 128 ? 32 : (batch <= 256 ? 64 : 32); // 64 x 64: fewer barriers while waves are few
+        const int    bk  = bm == 128 ? 32 : (batch <= 256 || split > 1 ? 64 : 32); // 64 x 64: fewer barriers while waves are few
         const size_t lds = (size_t)2 * (bm + bn) * (bk + 4) * sizeof(float);
-        if (bm == 128) {
+        if (split > 1) { // (64 x 64 tiles, 64-steps: the slices are whole numbers of them)
+            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64, true>, lds, device);
+            if (rc_lds != NVK_OK)
+                return rc_lds;
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<64, 64, 64, true>), dim3((unsigned)wgs), dim3(256), lds, st, p);
+        }
+        else if (bm == 128) {
             int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<128, 128, 32>, lds, device);
             if (rc_lds != NVK_OK)
                 return rc_lds;

@@ -108,6 +108,37 @@ def test_matmul_shapes_against_the_checker(B, D, N, nv, DA):
     assert close(got, want), float(np.abs(got - want).max())
 
 
+@pytest.mark.parametrize("B,D,N", [(128, 5632, 2048), (100, 2052, 200), (256, 4096, 1000), (97, 1024, 65),
+                                    (200, 8192, 64), (130, 516, 2048)])
+def test_split_k_tiles_against_the_checker_with_changing_inputs(B, D, N, nv, DA):
+    """More rows than the weight-streaming kernel takes and too few 64 x 64 tiles for the chip: the contraction is cut
+    into slices (nvk_gemm_nt_kernel<64, 64, 64, true>), a workgroup per (tile, slice), partial tiles handed over
+    through an arrival counter and added in slice order by whoever comes last.  A wrong hand-off shows as stale or
+    missing partials, so: three calls in a row with different activations, each against the checker; the same call
+    twice gives the same bits (the order of the sums does not depend on who arrives last); and a row's result does
+    not depend on its place in the batch.  k tails that are not multiples of 64, ragged rows and columns."""
+    w = (uniform(1701 + N, 0, N * D) * np.float32(1.0 / np.sqrt(D))).reshape(N, D)
+    dw = DA(w)
+    out = DA(np.full((B, N), np.nan, np.float32))
+    first = None
+    for rnd in range(3):
+        x = (uniform(1700 + 7 * rnd + B, 0, B * D) * np.float32(1 + rnd)).reshape(B, D)
+        want = ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x, w)
+        nv.batch_matmul_device(out, DA(x), dw, B, D, N)
+        got = out.numpy()
+        assert close(got, want), (rnd, float(np.abs(got - want).max()))
+        if rnd == 0:
+            first = (x, got)
+    x, got = first
+    nv.batch_matmul_device(out, DA(x), dw, B, D, N)
+    assert np.array_equal(out.numpy(), got)
+    perm = np.random.default_rng(B).permutation(B)
+    nv.batch_matmul_device(out, DA(x[perm]), dw, B, D, N)
+    assert np.array_equal(out.numpy(), got[perm])
+    nv.batch_matmul_device(out, DA(x * np.float32(2)), dw, B, D, N)
+    assert np.array_equal(out.numpy(), got * np.float32(2))
+
+
 def test_llama_size_projection_sampled_rows_and_exact_properties(nv, DA):
     """dim 4096 -> 32 q-heads + 8 kv-heads x 128 at 512 rows: sampled rows against the checker, and two properties
     that hold bit for bit at any size: scaling the input by 2 doubles every output (power-of-two scaling commutes
