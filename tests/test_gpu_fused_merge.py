@@ -230,3 +230,36 @@ def test_long_chunks_skewed_between_even_and_odd_xcds(bs, n, T, chunk):
         assert same_bits(p2, s2) and same_bits(p2, h2)
         assert_close(p2, want2, f"ragged, planned bs={bs}")
         assert_close(d2, want2, f"ragged, no plan bs={bs}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_skewed_chunks_on_random_long_batches(seed):
+    """Random batches cut into 1024- or 2048-token chunks (the sizes that are skewed): sequences with 0..5 full chunks
+    at even and odd places of the work list, ragged last chunks, an empty sequence, block sizes 16 and 24.  Planned
+    launch with either combine (same bits), the host-pointer entry point (same bits: it builds the same list), the
+    plan-free launch (tolerance: other bounds) -- all against the checker."""
+    d = wl.splitmix64(7700 + seed, np.arange(8, dtype=np.uint64)).tolist()
+    bs = (16, 24)[d[0] % 2]
+    chunk = (1024, 2048)[d[1] % 2]
+    n = 3 + d[2] % 6
+    g = wl.Geometry(32, 8, 128, bs)
+    ctx = (wl.splitmix64(seed + 50, np.arange(n, dtype=np.uint64)) % np.uint64(5 * chunk + 700)).astype(np.int32)
+    ctx[d[3] % n] = 0
+    ctx[(d[3] + 1) % n] = 3 * chunk  # an odd number of full chunks, no remainder: the next sequence starts at an odd place
+    work = wl.fragmented_workload(f"skewfuzz{seed}", ctx, g, slack=0.2, perm_seed=seed)
+    q = work.q()
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(n)))
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, bs, g.n_kv_heads, n_threads=4)
+    with nv.PagedKVPool(1, work.num_blocks, bs, g.n_kv_heads, g.head_dim) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        what = f"bs{bs} chunk{chunk} ctx{ctx.tolist()}"
+        fused = decode_dev(pool, work, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
+        apart = decode_dev(pool, work, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_SEPARATE, chunk)
+        host = nv.decode(pool, 0, q, work.block_tables, ctx, nv.SPLIT_K | nv.MERGE_IN_KERNEL, chunk)
+        free = decode_dev(pool, work, q, work.block_tables, ctx, nv.SPLIT_K | nv.NO_PLAN, chunk)
+        auto = decode_dev(pool, work, q, work.block_tables, ctx, nv.AUTO)
+        assert same_bits(fused, apart), what
+        assert same_bits(fused, host), what
+        assert_close(fused, want, what)
+        assert_close(free, want, what + " no plan")
+        assert_close(auto, want, what + " auto")
