@@ -82,6 +82,9 @@
 #ifndef NVK_SKINNY16_WIDE
 #define NVK_SKINNY16_WIDE 1 // 17-64 rows over few columns: 16 x 16 tiles, one workgroup per row tile (0: 32 x 32 tiles)
 #endif
+#ifndef NVK_SKINNY16_SPLIT
+#define NVK_SKINNY16_SPLIT 1 // up to 16 rows over at most half as many 16-column tiles as CUs: the contraction cut into slices
+#endif
 #ifndef NVK_NT_SPLIT_MIN_ROWS
 #define NVK_NT_SPLIT_MIN_ROWS 97 // from here a plain product whose 64 x 64 tiles leave CUs idle is cut along k (nvk_gemm_nt_kernel<.., SPLIT>)
 #endif
@@ -507,23 +510,35 @@ __device__ __forceinline__ void rope_append_store(const RopeAppendTarget &t, int
 // than the two products followed by the element-wise kernel.
 enum { kSkinnyPlain = 0, kSkinnyResid = 1, kSkinnyRope = 2 };
 
-template <int T, int TM, int BK, int EPI = kSkinnyPlain, bool SCALE = false>
+// SPLIT (T = 16, TM = 1, plain): few column tiles (2048 columns are 128 of them, half the CUs) -- the contraction is cut
+// into p.ksplit slices, a workgroup per (tile, slice); the slices' 16 x 16 partial tiles meet as in
+// nvk_gemm_nt_kernel<.., SPLIT> (write-through stores, an arrival counter per tile, added in slice order by whoever
+// comes last; only the workgroup's first wave is involved).
+template <int T, int TM, int BK, int EPI = kSkinnyPlain, bool SCALE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(const LinearParams p)
 {
     static_assert((EPI == kSkinnyPlain && !SCALE) || (T == 16 && TM == 1 && BK == 64)
                       || (EPI == kSkinnyRope && !SCALE && T == 32 && TM == 1 && BK == 64),
                   "epilogues: the 16 x 16 tile kernel; RoPE + append also on 32 x 32 tiles");
+    static_assert(!SPLIT || (T == 16 && TM == 1 && EPI == kSkinnyPlain && !SCALE), "split contraction: the plain 16 x 16 tile kernel");
     __shared__ float s_ssq[16]; // SCALE: every row's sum of squares
     constexpr int LDS = BK + 4;             // row stride in LDS (floats)
     constexpr int LPR = BK / 4, RPI = 64 / LPR; // lanes per tile row, rows per load instruction
     constexpr int RW = T / RPI, RX = TM * T / RPI; // float4 per lane per step: weights, activations
     extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [waves][(TM + 1) * T][LDS]
+    int bid = blockIdx.x, slice = 0;
+    if (SPLIT) { // slices outermost
+        const int per = gridDim.x / p.ksplit;
+        slice         = bid / per;
+        bid -= slice * per;
+    }
     const int span = 8 * p.m_tiles;
-    const int rem  = blockIdx.x % span;
-    const int nt   = blockIdx.x / span * 8 + rem % 8;
+    const int rem  = bid % span;
+    const int nt   = bid / span * 8 + rem % 8;
     const int m0   = rem / 8 * (TM * T);
     if (nt >= p.n_tiles)
         return;
+    const int kbeg = SPLIT ? slice * p.kslice : 0, kend = SPLIT ? min(p.k, kbeg + p.kslice) : p.k;
     const LinearSeg sg = segment_of(p, nt);
     const int       n0 = (nt - sg.tile0) * T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -541,13 +556,13 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
         woff[i] = min(n0 + lr + RPI * i, sg.n - 1) * p.k + lc;
     float4 rx[RX], rw0[RW], rw1[RW];
     auto   fetch_w = [&](float4(&r)[RW], int k0) {
-        const bool inside = k0 + lc < p.k;
+        const bool inside = k0 + lc < kend;
 #pragma unroll
         for (int i = 0; i < RW; i++)
             r[i] = inside ? load_stream(sg.w + woff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto fetch_x = [&](int k0) {
-        const bool inside = k0 + lc < p.k;
+        const bool inside = k0 + lc < kend;
 #pragma unroll
         for (int i = 0; i < RX; i++)
             rx[i] = inside ? *reinterpret_cast<const float4 *>(p.a + aoff[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -600,13 +615,13 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
         }
     };
 
-    const int nk    = (p.k + BK - 1) / BK;
+    const int nk    = (kend - kbeg + BK - 1) / BK;
     const int steps = nk > wave ? (nk - wave + kSkinnyWaves - 1) / kSkinnyWaves : 0; // this wave's share
     // Every workgroup starts the contraction somewhere else (a function of its column tile only, so an output's
     // summation order does not depend on its row): rows of W are in_dim * 4 bytes apart, and workgroups walking k
     // in lockstep would all be asking the same few HBM channels for the same 256-byte column of every row.
     const int rot   = NVK_K_ROTATE ? (int)(((unsigned)nt * 37u) % (unsigned)nk) : 0;
-    auto      k_of  = [&](int s) { return ((wave + s * kSkinnyWaves + rot) % nk) * BK; };
+    auto      k_of  = [&](int s) { return kbeg + ((wave + s * kSkinnyWaves + rot) % nk) * BK; };
     if (steps > 0) {
         fetch_w(rw0, k_of(0));
         fetch_x(k_of(0));
@@ -724,6 +739,35 @@ __global__ void __launch_bounds__(64 * kSkinnyWaves) nvk_gemm_skinny_kernel(cons
                 sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
             }
             const int row = m0 + t * T + (T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * pt : 4 * pt + r);
+            if constexpr (SPLIT) { // (tid < 64: the first wave alone, all its lanes)
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                constexpr int        kSc1 = 16; // aux bit 4 of the buffer instructions on gfx950: write-through
+                const int            tile = (rem / 8) * p.n_tiles + nt;
+                float               *all  = p.part + (int64_t)tile * p.ksplit * 256;
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc(all + slice * 256, 0, 256 * 4, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rs, tid * 16, 0, kSc1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int last = 0;
+                if (tid == 0) {
+                    int      *cnt  = p.arrive + tile;
+                    const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last           = prev == p.ksplit - 1;
+                    if (last) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // zero again for the next launch
+                    }
+                }
+                last = __builtin_amdgcn_readfirstlane(last);
+                if (!last)
+                    return;
+                sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int sl = 0; sl < p.ksplit; sl++) {
+                    const float4 v = reinterpret_cast<const float4 *>(all + sl * 256)[tid];
+                    sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+                }
+            }
             if (EPI == kSkinnyRope) { // (T = 32; the host checked n % 4 == 0: a float4 is in or out)
                 if (row < p.m && col + 3 < sg.n) {
                     const int si = (p.nseg > 1 && nt >= p.seg[1].tile0) + (p.nseg > 2 && nt >= p.seg[2].tile0);
@@ -1516,6 +1560,34 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
                 hipLaunchKernelGGL((nvk_gemm_skinny_kernel<16, 1, 64, kSkinnyPlain, true>), grid, block, lds, st, p);
             HIP_TRY(hipGetLastError());
             return NVK_OK;
+        }
+        // up to 16 rows over so few column tiles that half the CUs or more would idle (2048 columns: 128 tiles): the
+        // contraction cut so that every CU has a workgroup, slices of at least 2048 -- 5632 -> 2048 at 16 rows 16.5 -> 12.8 us;
+        // with slices of 1024 the hand-over costs what the second half of the CUs brings (2048 -> 2048: 7.8 -> 8.4 us)
+        int sk_split = 1, sk_slice = in_dim;
+        if (t == 16 && tm == 1 && bk == 64 && p.m_tiles == 1 && NVK_SKINNY16_SPLIT && tiles * 2 <= cus) {
+            const int want = (int)std::min<long long>(std::min<long long>(cus / tiles, in_dim / 2048), 8);
+            if (want > 1) {
+                const int steps = (in_dim + 63) / 64, per = (steps + want - 1) / want;
+                sk_slice        = per * 64;
+                sk_split        = (steps + per - 1) / per;
+            }
+#ifdef NVK_LINEAR_ENV // A/B build
+            if (getenv("NVK_SKINNY16_SPLIT_OFF"))
+                sk_split = 1;
+#endif
+            SplitWorkspace ws;
+            if (sk_split > 1 && split_workspace(device, st, (size_t)tiles * sk_split * 256, (size_t)tiles, &ws)) {
+                p.ksplit = sk_split, p.kslice = sk_slice, p.part = ws.part, p.arrive = ws.arrive;
+                const void *fns = (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 64, nvk::kSkinnyPlain, false, true>;
+                int rc_lds = opt_in_lds(fns, lds, device);
+                if (rc_lds != NVK_OK)
+                    return rc_lds;
+                hipLaunchKernelGGL((nvk::nvk_gemm_skinny_kernel<16, 1, 64, nvk::kSkinnyPlain, false, true>),
+                                   dim3((unsigned)(wgs * sk_split)), block, lds, st, p);
+                HIP_TRY(hipGetLastError());
+                return NVK_OK;
+            }
         }
         const void  *fn  = t == 16 ? (tm == 2 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 2, 32>
                                       : bk == 32 ? (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 32>
