@@ -1230,9 +1230,11 @@ int opt_in_lds(const void *kernel, size_t lds_bytes, int device)
 }
 
 // Where the split-K launches of one stream keep their partial tiles and arrival counters: one buffer per (device,
-// stream), grown on demand and kept -- launches on one stream run one after the other, so they can share it; two
-// streams never do.  Allocating is not possible while the stream is being captured: the caller then takes the unsplit
-// path (an engine's first step of a shape runs uncaptured, which is when this grows).
+// stream), allocated the first time the stream needs it and NEVER moved or freed afterwards -- a captured graph holds
+// its address.  Launches on one stream run one after the other, so they can share it; two streams never do.  Its size
+// is what the largest cut launch can need (at most two workgroups per CU, a 64 x 64 tile each).  Allocating is not
+// possible while the stream is being captured: the caller then takes the uncut path (an engine's first step of a
+// shape runs uncaptured, which is when this is made).
 struct SplitWorkspace
 {
     float *part    = nullptr;
@@ -1248,21 +1250,19 @@ struct SplitKey
 };
 std::map<SplitKey, SplitWorkspace> g_split_ws;
 
-// returns false when the buffers are too small and cannot be grown now (stream capture in progress, or out of memory)
-bool split_workspace(int device, hipStream_t st, size_t floats, size_t counters, SplitWorkspace *out)
+// returns false when the stream has no buffer yet and none can be made now (stream capture in progress, out of memory),
+// or the request is larger than any cut launch is (cannot happen: see split_slices)
+bool split_workspace(int device, int cus, hipStream_t st, size_t floats, size_t counters, SplitWorkspace *out)
 {
     std::lock_guard<std::mutex> lock(g_split_mutex);
     SplitWorkspace &w = g_split_ws[SplitKey{device, st}];
-    if (w.floats < floats || w.counters < counters) {
+    if (!w.part) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
             (void)hipGetLastError();
             return false;
         }
-        // whatever ran on this stream with the old buffers is done before they go
-        if (hipStreamSynchronize(st) != hipSuccess)
-            return false;
-        const size_t nf = std::max(floats, w.floats * 2), nc = std::max<size_t>(std::max(counters, w.counters * 2), 1024);
+        const size_t nf = (size_t)2 * cus * 64 * 64, nc = (size_t)2 * cus;
         float       *pf = nullptr;
         int         *pc = nullptr;
         if (hipMalloc(&pf, nf * sizeof(float)) != hipSuccess || hipMalloc(&pc, nc * sizeof(int)) != hipSuccess
@@ -1274,12 +1274,10 @@ bool split_workspace(int device, hipStream_t st, size_t floats, size_t counters,
                 (void)hipFree(pc);
             return false;
         }
-        if (w.part)
-            (void)hipFree(w.part);
-        if (w.arrive)
-            (void)hipFree(w.arrive);
         w.part = pf, w.arrive = pc, w.floats = nf, w.counters = nc;
     }
+    if (w.floats < floats || w.counters < counters)
+        return false;
     *out = w;
     return true;
 }
@@ -1386,7 +1384,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     if (!glu && !rope && !link && batch >= split_min_rows && batch > NVK_GEMV_MAX_ROWS && NVK_GEMM_FORCE_TILE != 128) {
         split = split_slices(t64, in_dim, cus, &kslice);
         SplitWorkspace ws;
-        if (split > 1 && split_workspace(device, st, (size_t)t64 * split * 64 * 64, (size_t)t64, &ws))
+        if (split > 1 && split_workspace(device, cus, st, (size_t)t64 * split * 64 * 64, (size_t)t64, &ws))
             p.ksplit = split, p.kslice = kslice, p.part = ws.part, p.arrive = ws.arrive;
         else
             split = 1;
@@ -1577,7 +1575,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
                 sk_split = 1;
 #endif
             SplitWorkspace ws;
-            if (sk_split > 1 && split_workspace(device, st, (size_t)tiles * sk_split * 256, (size_t)tiles, &ws)) {
+            if (sk_split > 1 && split_workspace(device, cus, st, (size_t)tiles * sk_split * 256, (size_t)tiles, &ws)) {
                 p.ksplit = sk_split, p.kslice = sk_slice, p.part = ws.part, p.arrive = ws.arrive;
                 const void *fns = (const void *)nvk::nvk_gemm_skinny_kernel<16, 1, 64, nvk::kSkinnyPlain, false, true>;
                 int rc_lds = opt_in_lds(fns, lds, device);
