@@ -88,6 +88,9 @@
 #ifndef NVK_NT_SPLIT_MIN_ROWS
 #define NVK_NT_SPLIT_MIN_ROWS 97 // from here a plain product whose 64 x 64 tiles leave CUs idle is cut along k (nvk_gemm_nt_kernel<.., SPLIT>)
 #endif
+#ifndef NVK_NT_SPLIT_FILL
+#define NVK_NT_SPLIT_FILL 2 // ... so that the launch is this many workgroups per CU (two fit)
+#endif
 #ifndef NVK_NT_SPLIT_MIN_K
 #define NVK_NT_SPLIT_MIN_K 256 // ... into slices of at least this many contraction steps
 #endif
@@ -1289,7 +1292,12 @@ int split_slices(long long tiles, int k, int cus, int *kslice)
     *kslice = k;
     if (tiles <= 0 || tiles >= cus)
         return 1;
-    int want = (int)std::min<long long>(16, 2LL * cus / tiles); // (no more workgroups than are resident at once)
+    int fill = NVK_NT_SPLIT_FILL;
+#ifdef NVK_LINEAR_ENV // A/B build
+    if (const char *e = getenv("NVK_NT_SPLIT_FILL"))
+        fill = atoi(e);
+#endif
+    int want = (int)std::min<long long>(16, (long long)fill * cus / tiles); // (no more workgroups than are resident at once)
     want     = std::min(want, std::max(1, k / NVK_NT_SPLIT_MIN_K));
     if (want <= 1)
         return 1;
