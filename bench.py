@@ -43,7 +43,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 GEOMS = {"llama": (32, 8, 128, 16), "mha": (32, 32, 128, 16), "tiny": (6, 6, 48, 16), "shard2": (16, 4, 128, 16),
          "shard8": (4, 1, 128, 16), "d64": (32, 8, 64, 16), "d256": (16, 4, 256, 16), "gqa8": (32, 4, 128, 16),
-         "kvmul3": (24, 8, 128, 16), "mha64": (64, 64, 128, 16), "tinyllama": (32, 4, 64, 16)}
+         "kvmul3": (24, 8, 128, 16), "mha64": (64, 64, 128, 16), "tinyllama": (32, 4, 64, 16),
+         "gqa8x8": (64, 8, 128, 16), "shard4": (8, 2, 128, 16)}
 
 
 def make_workload(name, rank=0, geom="llama"):

@@ -1002,7 +1002,7 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
                                    : xcd_range_item(item_i, p.num_seqs * p.max_chunks, p.xcd_ranges);
         seq     = item_i / p.max_chunks;
         chunk   = item_i - seq * p.max_chunks;
-        t0      = chunk * p.chunk_tokens;
+        t0      = chunk * p.chunk_tokens - (chunk & 1) * p.chunk_skew;
         ctx_raw = p.ctx_lens ? p.ctx_lens[seq] : p.uniform_ctx;
     }
     else {
@@ -1033,7 +1033,8 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
     }
 
     const int blk0 = token_block(t0, p.bs_magic);
-    const int blk_last = p.direct ? min(token_block(t0 + p.chunk_tokens - 1, p.bs_magic), p.max_blocks - 1)
+    const int chunk_len = p.chunk_tokens + ((chunk & 1) ? p.chunk_skew : -p.chunk_skew); // (direct launches)
+    const int blk_last = p.direct ? min(token_block(t0 + chunk_len - 1, p.bs_magic), p.max_blocks - 1)
                                   : (t1 > t0 ? token_block(t1 - 1, p.bs_magic) : blk0 - 1);
     const int trow = p.table_rows ? p.table_rows[seq] : seq;
     for (int i = threadIdx.x; i <= blk_last - blk0; i += blockDim.x)
@@ -1041,7 +1042,7 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
     if (p.direct) {
         const int ctx = min(max(ctx_raw, 0), p.max_chunks * p.chunk_tokens);
         nch           = (ctx + p.chunk_tokens - 1) / p.chunk_tokens;
-        t1            = min(ctx, t0 + p.chunk_tokens);
+        t1            = min(ctx, t0 + chunk_len);
         if (chunk >= max(nch, 1))
             return;
     }

@@ -64,6 +64,9 @@
 #ifndef NVK_XCD_SKEW_PERMILLE
 #define NVK_XCD_SKEW_PERMILLE 40 // thousandths of a chunk that an even XCD's chunk hands to the odd XCD's behind it ...
 #endif
+#ifndef NVK_XCD_SKEW_ALL_SHAPES
+#define NVK_XCD_SKEW_ALL_SHAPES 0 // 1: also token-split workgroups and the MFMA kernel (A/B)
+#endif
 #ifndef NVK_XCD_SKEW_MIN_CHUNK
 #define NVK_XCD_SKEW_MIN_CHUNK 1024 // ... in uniform batches cut into chunks of at least this many tokens (enqueue_planned)
 #endif
@@ -441,7 +444,9 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
     // every even XCD's full chunk hands a few tokens (whole steps) to the odd XCD's chunk behind it -- the even XCDs of
     // an MI355X stream 3-6 % slower than the odd ones and a launch ends with the slowest.  Measured: config 4 0.86-0.87
     // -> 0.88-0.89 of the HBM peak; 512-token chunks gain nothing (profiles/r03_xcd_balance.log).  The table slice
-    // in LDS gets room for the longer chunks.
+    // in LDS gets room for the longer chunks.  Only where it measured better: workgroups that stream whole 4-KiB token
+    // rows (8 kv-heads x 128 floats: the wide kernel, and the MFMA kernel at 64/8/128: +1.3 %); token-split workgroups
+    // (1-4 kv-heads) and 64-float rows LOSE 1-2.5 % to it (same log: NVK_XCD_SKEW_ALL_SHAPES).
     plan->chunk_skew = 0;
     {
         int permille = NVK_XCD_SKEW_PERMILLE, min_chunk = NVK_XCD_SKEW_MIN_CHUNK;
@@ -451,15 +456,19 @@ int make_shape(const nvk_pool *pool, int num_seqs, int n_heads, int max_ctx, int
         if (const char *e = getenv("NVK_XCD_SKEW_MIN_CHUNK"))
             min_chunk = atoi(e);
 #endif
-        if (permille > 0 && plan->parts == 1 && !plan->mfma && plan->kv_groups == 1 && plan->qpk == kv_mul
-            && plan->chunk_tokens >= min_chunk) {
-            const int step = plan->wide ? 16 : 8, room = plan->chunk_tokens / 16;
+        if (permille > 0 && plan->kv_groups == 1 && plan->qpk == kv_mul && plan->chunk_tokens >= min_chunk
+            && (NVK_XCD_SKEW_ALL_SHAPES || plan->wide || (plan->mfma && plan->parts == 1 && hd == 128))) {
+            const int step = plan->wide || plan->mfma ? 16 : 8, room = plan->chunk_tokens / 16;
             plan->chunk_skew = std::min((int)((long long)plan->chunk_tokens * permille / 1000 + step / 2) / step * step, room / step * step);
         }
     }
-    const int skew_room = plan->chunk_skew;
-    plan->merge_off    = ((plan->chunk_tokens + skew_room) / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
+    plan->merge_off    = ((plan->chunk_tokens + plan->chunk_skew) / pool->block_size + 2 + 3) / 4 * 4; // 16-B aligned behind the table slice
     plan->lds_bytes    = (size_t)plan->merge_off * sizeof(int) + merge_bytes;
+    if (plan->chunk_skew > 0 && plan->lds_bytes > (size_t)kLdsPerLaunch) { // (a chunk as long as the LDS allows: no room to skew)
+        plan->chunk_skew = 0;
+        plan->merge_off  = (plan->chunk_tokens / pool->block_size + 2 + 3) / 4 * 4;
+        plan->lds_bytes  = (size_t)plan->merge_off * sizeof(int) + merge_bytes;
+    }
     if (plan->lds_bytes > (size_t)kLdsPerLaunch) // (cannot happen: the chunk was bounded for it above)
         return nvk::fail(NVK_ERR_INVALID_ARG, "decode: the launch needs %zu bytes of LDS, more than %d", plan->lds_bytes,
                          kLdsPerLaunch);
@@ -767,11 +776,13 @@ int enqueue_planned(nvk_pool *pool, int layer, const nvk_plan *plan, const float
     // LaunchShape::chunk_skew without a plan: every chunk full, an even number of them per sequence, whole rounds of the
     // 8 XCDs -- the XCDs take their ranges in pairs, even chunks on even XCDs (with a plan the work list carries the
     // chunks' bounds: nvk::skewed_chunk)
+    // (token-split shapes keep item = workgroup id, which puts even chunks on even XCDs by itself)
     p.chunk_skew = 0;
-    if (p.xcd_ranges && sh.chunk_skew > 0 && sh.max_chunks % 2 == 0 && plan->uniform_ctx == sh.max_chunks * sh.chunk_tokens
-        && ((long long)plan->num_seqs * sh.max_chunks) % 8 == 0) {
+    if (plan->direct && !plan->ctx_lens_dev && sh.chunk_skew > 0 && sh.max_chunks % 2 == 0
+        && plan->uniform_ctx == sh.max_chunks * sh.chunk_tokens && ((long long)plan->num_seqs * sh.max_chunks) % 8 == 0) {
         p.chunk_skew = sh.chunk_skew;
-        p.xcd_ranges = 2;
+        if (p.xcd_ranges)
+            p.xcd_ranges = 2;
     }
 #ifdef NVK_STAMPS
     p.stamps = g_debug_stamps;

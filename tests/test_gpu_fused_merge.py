@@ -191,8 +191,9 @@ def test_uniform_batches_of_any_size_cover_every_item(n):
             assert same_bits(planned, uniform), f"n={n} mode 0x{mode:x}"
 
 
-@pytest.mark.parametrize("bs,n,T,chunk", [(16, 4, 4096, 1024), (24, 8, 2048, 1024), (16, 2, 8192, 2048)])
-def test_long_chunks_skewed_between_even_and_odd_xcds(bs, n, T, chunk):
+@pytest.mark.parametrize("bs,n,T,chunk,H", [(16, 4, 4096, 1024, 32), (24, 8, 2048, 1024, 32), (16, 2, 8192, 2048, 32),
+                                             (16, 4, 4096, 1024, 64), (24, 4, 4096, 2048, 64)])  # 64/8/128: the MFMA kernel
+def test_long_chunks_skewed_between_even_and_odd_xcds(bs, n, T, chunk, H):
     """Sequences cut into long chunks (>= 1024 tokens): every full chunk that runs on an even XCD hands 4 % of its
     tokens to the chunk behind it on the odd XCD beside it (LaunchShape::chunk_skew: the even XCDs stream slower).
     With a plan the work list carries the bounds (nvk::skewed_chunk, by the item's place in the list); without one
@@ -200,7 +201,7 @@ def test_long_chunks_skewed_between_even_and_odd_xcds(bs, n, T, chunk):
     Chunk bounds that no longer sit on multiples of the chunk size -- nor, at block size 24, on block boundaries:
     both combines give the same bits, every row matches the checker, and -- the same bounds either way here -- the
     planned and the plan-free launch give the same bits.  One token short of full chunks only the plan skews."""
-    g = wl.Geometry(32, 8, 128, bs)
+    g = wl.Geometry(H, 8, 128, bs)
     ctx = np.full(n, T, np.int32)
     work = wl.fragmented_workload(f"skew{bs}x{n}x{T}", ctx, g, perm_seed=bs + n)
     q = work.q()
