@@ -48,6 +48,9 @@
 #ifndef NVK_NT_LOADS
 #define NVK_NT_LOADS 1 // 1: K/V loads carry the non-temporal hint (read-once stream)
 #endif
+#ifndef NVK_MFMA_LOCKSTEP
+#define NVK_MFMA_LOCKSTEP 1 // 1: the same in nvk_decode_mfma_kernel where a workgroup's waves are 8 kv-heads; 2: token parts too; 0 for A/B
+#endif
 #ifndef NVK_LOCKSTEP
 #define NVK_LOCKSTEP 1 // 1: the waves of a workgroup are kept on the same token rows (see decode_body); 0 for A/B
 #endif
@@ -1172,11 +1175,22 @@ template <int HD> __global__ void __launch_bounds__(512, 1) nvk_decode_mfma_kern
 
     const std::integral_constant<bool, false> body;
     const std::integral_constant<bool, true>  tail;
+    // Lockstep, as in decode_body: left alone the older wave of each SIMD runs 1.4 x faster than the younger one here
+    // (2048-token chunks of 64/8/128: main loops of 434 and 602 us, profiles/r03_mfma_lockstep.log), and once the older
+    // four have ended the CU streams with half its loads in flight.  A bare s_barrier at the top of every double-step
+    // keeps the eight within one: 64/8/128 at config-2 size 0.745 -> 0.792 of the HBM peak, at 16 x 32K 0.824 -> 0.832.
+    // Only where the eight waves are the kv-heads of the same rows: with token parts (1-4 kv-heads) it measured +1.5 % at
+    // config-2 size and -1 ... -2 % on long chunks and on 5a (NVK_MFMA_LOCKSTEP=2 locks those too).
+    const int locked_upto = NVK_MFMA_LOCKSTEP && p.n_kv_heads == p.kv_waves && (parts == 1 || NVK_MFMA_LOCKSTEP == 2)
+                                ? (t1 - t0 + kStepTokens - 1) / kStepTokens / parts // steps of the part with the fewest
+                                : 0;
     if (has_tokens) {
         Tile ta, tb;
         int  k = 0;
         load_tile(ta, w0);
         for (; k + 2 < nsteps; k += 2) {
+            if (NVK_MFMA_LOCKSTEP && k + 2 < locked_upto)
+                __builtin_amdgcn_s_barrier();
             load_tile(tb, w0 + (k + 1) * stride);
             consume_tile(ta, w0 + k * stride, body);
             load_tile(ta, w0 + (k + 2) * stride);
