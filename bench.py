@@ -216,6 +216,7 @@ def cpu_baseline(work, cores):
 
 EXTRA_STEPS = 20    # layer-calls per timed region of an extra workload
 EXTRA_REGIONS = 5   # regions per extra workload: ms_per_step = their median, ms_per_step_min = the fastest
+EXTRA_WARMUP = 5    # untimed layer-calls in front of every region (the default run's --warmup)
 
 
 def extra_workloads(nv, torch, dev, args):
@@ -224,7 +225,10 @@ def extra_workloads(nv, torch, dev, args):
     of EXTRA_STEPS layer-calls each: the median region is the number, the fastest is beside it (box-to-box and
     region-to-region spread is 1-4 % on these)."""
     res = {}
-    for name in ("config3", "config4", "5a", "5b", "config2_head_shard_rank"):
+    names = ("config3", "config4", "5a", "5b", "config2_head_shard_rank")
+    if os.environ.get("NVK_BENCH_EXTRAS"):  # diagnostic: a subset, in the order given
+        names = tuple(n for n in os.environ["NVK_BENCH_EXTRAS"].split(",") if n in names)
+    for name in names:
         # (the last one: what each GPU of an 8-way head-sharded config 2 runs -- 4 q-heads / 1 kv-head of every sequence)
         work = make_workload("config2", 0, "shard8") if name == "config2_head_shard_rank" else make_workload(name)
         g = work.geom
@@ -246,9 +250,11 @@ def extra_workloads(nv, torch, dev, args):
             est_ms, _ = run(3, 3, False)
             # the same clock pre-warm as the headline's (the GPU idled while the host built this workload's tables)
             run(min(2000, int(args.prewarm_ms / max(est_ms, 1e-3)) + 1), 0, False)
-            regions = [run(0, EXTRA_STEPS, False)[0] for _ in range(EXTRA_REGIONS)]
+            # (every region with EXTRA_WARMUP untimed layer-calls in front of it inside the same call, as the headline's W
+            # warmup steps are: between two regions the host synchronises and the GPU idles)
+            regions = [run(EXTRA_WARMUP, EXTRA_STEPS, False)[0] for _ in range(EXTRA_REGIONS)]
             step_ms, step_min = statistics.median(regions), min(regions)
-            kregions = [run(0, EXTRA_STEPS, True)[1] for _ in range(EXTRA_REGIONS)]
+            kregions = [run(EXTRA_WARMUP, EXTRA_STEPS, True)[1] for _ in range(EXTRA_REGIONS)]
             attn_ms = statistics.median(kregions)
             out.fill_(float("nan"))
             run(0, 1, False)
@@ -259,7 +265,7 @@ def extra_workloads(nv, torch, dev, args):
             if not uniform_batch:
                 # what an engine does: the plan depends on the lengths only, so it is built once per model step and
                 # serves all of its layer-calls (nvk_plan_build + nvk_decode_planned); here once per 32 launches
-                rr = [run(2 if i == 0 else 0, 32, False, 32)[0] for i in range(EXTRA_REGIONS)]
+                rr = [run(32, 32, False, 32)[0] for i in range(EXTRA_REGIONS)]
                 r_ms = statistics.median(rr)
                 reused = {"replan_every": 32, "steps": 32, "regions": EXTRA_REGIONS, "ms_per_step": round(r_ms, 4),
                           "ms_per_step_min": round(min(rr), 4),
@@ -270,6 +276,7 @@ def extra_workloads(nv, torch, dev, args):
             graph = {"layers_per_graph": 32, "launches": 5, "ms_per_step": round(g_ms, 4), "frac": frac(g_ms)}
             traffic, traffic_source = profiled_traffic(work.name, kname)
             res[name] = {"workload": work.name, "steps": EXTRA_STEPS, "regions": EXTRA_REGIONS,
+                         "warmup_per_region": EXTRA_WARMUP,
                          "ms_per_step": round(step_ms, 4), "ms_per_step_min": round(step_min, 4),
                          "GBps": round(nbytes / (step_ms * 1e-3) / 1e9, 1), "frac": frac(step_ms),
                          "frac_best_region": frac(step_min),
@@ -283,7 +290,17 @@ def extra_workloads(nv, torch, dev, args):
                 res[name]["plan_reused_over_32_layer_calls"] = reused
         del q, tabs, ctx, out
         torch.cuda.empty_cache()
+        settle(torch)
     return res
+
+
+def settle(torch, seconds=0.6):
+    """Between two workloads: the pool just freed was gigabytes, and for a few hundred milliseconds after a release of
+    that size the next workload's launches measure 3-4 % slower (config 4 right after config 3 or 5b: 0.859 of the peak
+    for the first ~150 ms of launches, 0.892 after that and when it runs first -- profiles/r03_extras_order.log).
+    The wait keeps one workload's clean-up out of the next one's number."""
+    torch.cuda.synchronize()
+    time.sleep(seconds)
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz)
