@@ -753,6 +753,7 @@ def multi_gpu_workloads(nv, torch, dist, args, rank, world, local_rank, dev, red
             publish()
             del q, tabs, ctx, out
         torch.cuda.empty_cache()
+        settle(torch)
 
     full = wl.config5b(512 * world)
     gf = full.geom
@@ -1097,6 +1098,7 @@ def main():
             pool = None
             del q, tabs, ctx, out
             torch.cuda.empty_cache()
+            settle(torch)
             if not args.no_extra:
                 line["workloads"] = extra_workloads(nv, torch, dev, args)
             if not args.no_frows:
