@@ -65,10 +65,10 @@
 #define NVK_XCD_SKEW_PERMILLE 40 // thousandths of a chunk that an even XCD's chunk hands to the odd XCD's behind it ...
 #endif
 #ifndef NVK_XCD_SKEW_ALL_SHAPES
-#define NVK_XCD_SKEW_ALL_SHAPES 0 // 1: also token-split workgroups and the MFMA kernel (A/B)
+#define NVK_XCD_SKEW_ALL_SHAPES 0 // 1: also token-split workgroups, 64-float rows and every MFMA shape (A/B: they lose)
 #endif
 #ifndef NVK_XCD_SKEW_MIN_CHUNK
-#define NVK_XCD_SKEW_MIN_CHUNK 1024 // ... in uniform batches cut into chunks of at least this many tokens (enqueue_planned)
+#define NVK_XCD_SKEW_MIN_CHUNK 1024 // ... where sequences are cut into chunks of at least this many tokens (make_shape)
 #endif
 #ifndef NVK_POOL_SKEW_BYTES
 #define NVK_POOL_SKEW_BYTES 0 // bytes of padding behind every slab of the one-allocation layout (a multiple of 256)
