@@ -183,7 +183,8 @@ int nvk_pool_rope_append_chunks(nvk_pool *pool, int layer, int num_seqs, int n_h
  *        in_dim a multiple of 4, in/weight 16-byte aligned.  Up to 96 rows the weights are streamed once
  *        (HBM-bound); more: 64x64 or 128x128 tiles on fp32 MFMA.  Where those tiles are fewer than the CUs the
  *        contraction is cut into slices (a workgroup per tile and slice, added in slice order: the same bits
- *        every time); the partial tiles live in a buffer the library keeps per (device, stream) -- 8 MiB on
+ *        every time; or the k-steps of all tiles are dealt evenly over the CUs, stream-K); the partial tiles live
+ *        in a buffer the library keeps per (device, stream) -- 16 MiB on
  *        256 CUs, allocated the first time a stream needs it and never moved (a captured graph may hold its
  *        address) -- not under stream capture, where a stream without one takes the uncut path.
  * nvk_qkv_project_device      the head of a layer, include/core/model.hpp:161-166 (forward_chunk:

@@ -88,6 +88,15 @@
 #ifndef NVK_NT_SPLIT_MIN_ROWS
 #define NVK_NT_SPLIT_MIN_ROWS 97 // from here a plain product whose 64 x 64 tiles leave CUs idle is cut along k (nvk_gemm_nt_kernel<.., SPLIT>)
 #endif
+#ifndef NVK_NT_STREAM_MIN_ROWS
+#define NVK_NT_STREAM_MIN_ROWS 33 // from here a plain product runs nvk_gemm_nt_kernel<64, 64, 64, kNtStream> (stream-K) where ...
+#endif
+#ifndef NVK_NT_STREAM_MAX_TILES_PER_CU
+#define NVK_NT_STREAM_MAX_TILES_PER_CU 3 // ... its 64 x 64 tiles are fewer than this many per CU (more: plain tiles balance by themselves)
+#endif
+#ifndef NVK_NT_STREAM_FILL
+#define NVK_NT_STREAM_FILL 2 // workgroups per CU of a stream-K launch
+#endif
 #ifndef NVK_NT_SPLIT_FILL
 #define NVK_NT_SPLIT_FILL 2 // ... so that the launch is this many workgroups per CU (two fit)
 #endif
@@ -249,26 +258,57 @@ __global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ o
 // write-through (sc1), the one whose arrival completes the tile (agent-scope counter, the protocol of the decode
 // kernel's split-K combine, nvk_kernels.hip.h) adds the slices IN SLICE ORDER -- the same bits whoever comes last --
 // and stores the tile.  Nobody waits for anybody.
-template <int BM, int BN, int BK, bool SPLIT = false>
+// MODE kNtStream (stream-K): per row tile, the (column tile, k-step) pairs laid end to end and cut into equal runs of
+// p.kslice steps, p.ksplit runs to a row tile, a workgroup per run -- every CU gets the same number of MFMA steps
+// whatever the number of tiles (64 rows x 11264 columns are 176 tiles: 1.4 per CU cut in two, 0.7 whole).  A run covers
+// the tail of one tile, whole tiles, and the head of another; a tile that several runs share is completed as in
+// kNtSplit, its pieces added in run order.  The cuts of a column tile are the same in every row tile, so an output's
+// summation order still does not depend on its row.  A workgroup's piece of a tile lies in slot 2 g (the tile its run
+// starts in) or 2 g + 1 (a later one) of p.part.
+enum { kNtPlain = 0, kNtSplit = 1, kNtStream = 2 };
+template <int BM, int BN, int BK, int MODE = kNtPlain>
 __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams p)
 {
+    constexpr bool SPLIT = MODE == kNtSplit, STREAM = MODE == kNtStream;
     constexpr int TA = BM / 64, TB = BN / 64; // 32 x 32 MFMA tiles per wave along the rows / the columns
     constexpr int kGemmBK = BK, kGemmLds = BK + 4, KV = BK / 32; // KV: float4 per thread per tile row pass
     extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [2][BM + BN][kGemmLds]
+    __shared__ int s_last;
 
-    int bid = blockIdx.x, slice = 0;
-    if (SPLIT) { // slices outermost: the workgroups of one slice are dealt as an unsplit launch's
-        const int per = gridDim.x / p.ksplit;
-        slice         = bid / per;
-        bid -= slice * per;
+    // kNtStream: this workgroup's run [pos, pos_end) of its row tile's k-steps, nk_tile of them to a tile
+    const int nk_tile = (p.k + BK - 1) / BK;
+    int       pos = 0, pos_end = 0, run_mt = 0, run_g = 0;
+    if (STREAM) {
+        run_mt  = blockIdx.x / p.ksplit;
+        run_g   = blockIdx.x - run_mt * p.ksplit;
+        pos     = run_g * p.kslice;
+        pos_end = min(pos + p.kslice, p.n_tiles * nk_tile);
+        if (pos >= pos_end)
+            return;
     }
-    const int span = 8 * p.m_tiles;
-    const int rem  = bid % span;
-    const int nt   = bid / span * 8 + rem % 8;
-    const int mt   = rem / 8;
-    if (nt >= p.n_tiles)
-        return; // (padding of the grid: no slice of such a tile exists, nobody counts on it)
-    const int kbeg = SPLIT ? slice * p.kslice : 0, kend = SPLIT ? min(p.k, kbeg + p.kslice) : p.k;
+  for (;;) { // (kNtPlain / kNtSplit: once)
+    int bid = blockIdx.x, slice = 0, nt, mt, kbeg, kend, run_steps = 0;
+    if (STREAM) {
+        nt          = pos / nk_tile;
+        mt          = run_mt;
+        const int a = pos - nt * nk_tile;
+        run_steps   = min(nk_tile - a, pos_end - pos);
+        kbeg = a * BK, kend = min(p.k, (a + run_steps) * BK);
+    }
+    else {
+        if (SPLIT) { // slices outermost: the workgroups of one slice are dealt as an unsplit launch's
+            const int per = gridDim.x / p.ksplit;
+            slice         = bid / per;
+            bid -= slice * per;
+        }
+        const int span = 8 * p.m_tiles;
+        const int rem  = bid % span;
+        nt             = bid / span * 8 + rem % 8;
+        mt             = rem / 8;
+        if (nt >= p.n_tiles)
+            return; // (padding of the grid: no slice of such a tile exists, nobody counts on it)
+        kbeg = SPLIT ? slice * p.kslice : 0, kend = SPLIT ? min(p.k, kbeg + p.kslice) : p.k;
+    }
     const LinearSeg sg = segment_of(p, nt);
     const int       n0 = (nt - sg.tile0) * BN, m0 = mt * BM;
 
@@ -387,12 +427,24 @@ __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams 
         }
     }
 
-    if (SPLIT) {
+    // a tile in pieces (kNtSplit: always; kNtStream: unless this run holds all of the tile's steps)
+    const bool pieces = SPLIT || (STREAM && run_steps != nk_tile);
+    bool       store  = true;
+    if (pieces) {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         constexpr int        kSc1  = 16; // aux bit 4 of the buffer instructions on gfx950: write-through
         constexpr int        kTile = BM * BN;
         const int            tile  = mt * p.n_tiles + nt;
-        float               *mine  = p.part + ((int64_t)tile * p.ksplit + slice) * kTile;
+        // kNtStream: the runs g_first .. g_last of this row tile share the tile
+        const int g_first = STREAM ? (nt * nk_tile) / p.kslice : 0;
+        const int n_piece = STREAM ? ((nt + 1) * nk_tile - 1) / p.kslice - g_first + 1 : p.ksplit;
+        auto      slot_of = [&](int i) { // the i-th piece of the tile, in the order of the sum
+            if (!STREAM)
+                return (int64_t)tile * p.ksplit + i;
+            const int g = g_first + i;
+            return (int64_t)2 * (mt * p.ksplit + g) + (nt != (g * p.kslice) / nk_tile ? 1 : 0);
+        };
+        float *mine = p.part + slot_of(STREAM ? run_g - g_first : slice) * kTile;
         // a thread's accumulators as float4s, [float4 index][thread]: coalesced both ways
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, kTile * 4, 0x00020000);
 #pragma unroll
@@ -405,13 +457,12 @@ __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams 
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
                                                            ((((a * TB + b) * 4 + q) * 256) + tid) * 16, 0, kSc1);
                 }
-        __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             int      *cnt  = p.arrive + tile;
             const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = prev == p.ksplit - 1;
+            const int last = prev == n_piece - 1;
             if (last) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -420,45 +471,54 @@ __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams 
             s_last = last;
         }
         __syncthreads();
-        if (!s_last)
+        store = s_last != 0;
+        if (!store && !STREAM)
             return;
-        const float *all = p.part + (int64_t)tile * p.ksplit * kTile;
-#pragma unroll
-        for (int a = 0; a < TA; a++)
-#pragma unroll
-            for (int b = 0; b < TB; b++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    acc[a][b][r] = 0.f;
-        for (int sl = 0; sl < p.ksplit; sl++) {
-            const float4 *src = reinterpret_cast<const float4 *>(all + (int64_t)sl * kTile) + tid;
+        if (store) {
 #pragma unroll
             for (int a = 0; a < TA; a++)
 #pragma unroll
                 for (int b = 0; b < TB; b++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 v = src[((a * TB + b) * 4 + q) * 256];
-                        acc[a][b][4 * q] += v.x, acc[a][b][4 * q + 1] += v.y, acc[a][b][4 * q + 2] += v.z,
-                            acc[a][b][4 * q + 3] += v.w;
-                    }
+                    for (int r = 0; r < 16; r++)
+                        acc[a][b][r] = 0.f;
+            for (int sl = 0; sl < n_piece; sl++) {
+                const float4 *src = reinterpret_cast<const float4 *>(p.part + slot_of(sl) * kTile) + tid;
+#pragma unroll
+                for (int a = 0; a < TA; a++)
+#pragma unroll
+                    for (int b = 0; b < TB; b++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float4 v = src[((a * TB + b) * 4 + q) * 256];
+                            acc[a][b][4 * q] += v.x, acc[a][b][4 * q + 1] += v.y, acc[a][b][4 * q + 2] += v.z,
+                                acc[a][b][4 * q + 3] += v.w;
+                        }
+            }
         }
     }
     // D[row][col]: col = lane & 31, register r holds row (r & 3) + 8 * (r >> 2) + 4 * half
+    if (store) {
 #pragma unroll
-    for (int a = 0; a < TA; a++)
+        for (int a = 0; a < TA; a++)
 #pragma unroll
-        for (int b = 0; b < TB; b++) {
-            const int col = n0 + wn * (BN / 2) + 32 * b + j;
+            for (int b = 0; b < TB; b++) {
+                const int col = n0 + wn * (BN / 2) + 32 * b + j;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + wm * (BM / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.m && col < sg.n)
-                    sg.out[(int64_t)row * sg.ldo + col] = acc[a][b][r];
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + wm * (BM / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < p.m && col < sg.n)
+                        sg.out[(int64_t)row * sg.ldo + col] = acc[a][b][r];
+                }
             }
-        }
+    }
+    if (!STREAM)
+        return;
+    pos += run_steps;
+    if (pos >= pos_end)
+        return;
+  }
 }
-
 // ---- C = A . W^T, few rows: stream the weights once -----------------------------------------------
 // One workgroup = a 32 x 32 output tile (32 weight rows), 8 waves, the contraction dealt round-robin
 // over the waves in steps of 64.  Every wave is on its own: it brings its 32 x 64 weight tile and the
@@ -1235,7 +1295,7 @@ int opt_in_lds(const void *kernel, size_t lds_bytes, int device)
 // Where the split-K launches of one stream keep their partial tiles and arrival counters: one buffer per (device,
 // stream), allocated the first time the stream needs it and NEVER moved or freed afterwards -- a captured graph holds
 // its address.  Launches on one stream run one after the other, so they can share it; two streams never do.  Its size
-// is what the largest cut launch can need (at most two workgroups per CU, a 64 x 64 tile each).  Allocating is not
+// is what the largest cut launch can need (at most two workgroups per CU, two 64 x 64 pieces each: 16 MiB on 256 CUs).  Allocating is not
 // possible while the stream is being captured: the caller then takes the uncut path (an engine's first step of a
 // shape runs uncaptured, which is when this is made).
 struct SplitWorkspace
@@ -1244,6 +1304,7 @@ struct SplitWorkspace
     int   *arrive  = nullptr;
     size_t floats  = 0, counters = 0;
 };
+constexpr size_t kSplitCounters = 16384; // tiles a cut launch may have (an arrival counter each)
 std::mutex g_split_mutex;
 struct SplitKey
 {
@@ -1265,7 +1326,7 @@ bool split_workspace(int device, int cus, hipStream_t st, size_t floats, size_t 
             (void)hipGetLastError();
             return false;
         }
-        const size_t nf = (size_t)2 * cus * 64 * 64, nc = (size_t)2 * cus;
+        const size_t nf = (size_t)4 * cus * 64 * 64, nc = kSplitCounters; // (stream-K: two pieces per workgroup, two workgroups per CU)
         float       *pf = nullptr;
         int         *pc = nullptr;
         if (hipMalloc(&pf, nf * sizeof(float)) != hipSuccess || hipMalloc(&pc, nc * sizeof(int)) != hipSuccess
@@ -1397,7 +1458,46 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         else
             split = 1;
     }
-    const bool skinny = batch <= NVK_SKINNY_MAX_ROWS && split == 1;
+    // ... or, for more rows than the weight-streaming kernel does well, the (tile, k-step) pairs dealt evenly over the CUs
+    int stream_steps = 0; // k-steps per workgroup of nvk_gemm_nt_kernel<64, 64, 64, kNtStream>; 0: not that kernel
+    {
+        int stream_min_rows = NVK_NT_STREAM_MIN_ROWS, stream_fill = NVK_NT_STREAM_FILL, stream_min_steps = 16;
+        bool stream_always = false;
+#ifdef NVK_LINEAR_ENV // A/B build
+        if (const char *e = getenv("NVK_NT_STREAM_MIN_STEPS")) // (0: wherever the kernel can run -- the tests' way in)
+            stream_min_steps = atoi(e), stream_always = stream_min_steps == 0;
+        if (const char *e = getenv("NVK_NT_STREAM_MIN_ROWS"))
+            stream_min_rows = atoi(e);
+        if (const char *e = getenv("NVK_NT_STREAM_FILL"))
+            stream_fill = atoi(e);
+#endif
+        long long n64 = 0;
+        for (int s = 0; s < nseg; s++)
+            n64 += (n[s] + 63) / 64;
+        const int       m64       = (batch + 63) / 64;
+        const long long row_steps = n64 * ((in_dim + 63) / 64); // k-steps of one row tile
+        // where it pays (profiles/r03_nt_streamk.log): at least 16 steps to a CU, and the kernel it replaces would leave
+        // a tenth of the chip idle or more -- plain tiles always do below 3 per CU, the cut tiles where their slices do
+        // not fill the slots
+        const bool cut_fills = split > 1 && t64 * split * 10 >= 2LL * cus * 9;
+        if (!glu && !rope && !link && batch >= stream_min_rows && batch > NVK_GEMV_MAX_ROWS && NVK_GEMM_FORCE_TILE != 128
+            && (t64 < (long long)NVK_NT_STREAM_MAX_TILES_PER_CU * cus || stream_always) && t64 <= (long long)kSplitCounters
+            && row_steps * m64 >= (long long)stream_min_steps * cus && row_steps < (1LL << 24) && (!cut_fills || stream_always)) {
+            long long per_row = std::max<long long>(1, (long long)stream_fill * cus / m64); // runs to a row tile
+            if (m64 > 1)
+                per_row = std::max<long long>(8, per_row / 8 * 8); // (the row tiles' runs over one k-range on one XCD)
+            per_row = std::min(per_row, row_steps);
+            const long long per = (row_steps + per_row - 1) / per_row; // steps to a run
+            per_row             = (row_steps + per - 1) / per;
+            SplitWorkspace ws;
+            if (per >= 2 && split_workspace(device, cus, st, (size_t)2 * per_row * m64 * 64 * 64, (size_t)t64, &ws)) {
+                stream_steps = (int)per;
+                split        = 1;
+                p.ksplit = (int)per_row, p.kslice = stream_steps, p.part = ws.part, p.arrive = ws.arrive;
+            }
+        }
+    }
+    const bool skinny = batch <= NVK_SKINNY_MAX_ROWS && split == 1 && stream_steps == 0;
     p.a = in, p.m = batch, p.k = in_dim, p.lda = in_dim;
     const bool t16 = tile16(batch, n, nseg, cus);
     // fused epilogues beyond the GEMV: the norm link in the 16 x 16 tile kernel up to 16 rows; RoPE + append wherever the
@@ -1438,7 +1538,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         // measured (profiles/r01_qkv_projection.log): two 128 x 128 workgroups fit a CU, and a launch that is not
         // at least three full rounds of them loses more to the ragged last round than 64 x 64 tiles lose to their
         // four times higher LDS and L2 traffic per flop
-        if (split > 1 || NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
+        if (split > 1 || stream_steps > 0 || NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
             bm = bn = 64;
     }
     else
@@ -1623,13 +1723,20 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         const long long wgs = (tiles + 7) / 8 * 8 * p.m_tiles * split;
         if (wgs > 0x7fffffffLL)
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
-        const int    bk  = bm == 128 ? 32 : (batch <= 256 || split > 1 ? 64 : 32); // 64 x 64: fewer barriers while waves are few
+        const int    bk  = bm == 128 ? 32 : (batch <= 256 || split > 1 || stream_steps > 0 ? 64 : 32); // 64 x 64: fewer barriers while waves are few
         const size_t lds = (size_t)2 * (bm + bn) * (bk + 4) * sizeof(float);
-        if (split > 1) { // (64 x 64 tiles, 64-steps: the slices are whole numbers of them)
-            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64, true>, lds, device);
+        if (stream_steps > 0) { // (64 x 64 tiles, 64-steps)
+            const long long grid = (long long)p.ksplit * p.m_tiles;
+            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64, nvk::kNtStream>, lds, device);
             if (rc_lds != NVK_OK)
                 return rc_lds;
-            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<64, 64, 64, true>), dim3((unsigned)wgs), dim3(256), lds, st, p);
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<64, 64, 64, nvk::kNtStream>), dim3((unsigned)grid), dim3(256), lds, st, p);
+        }
+        else if (split > 1) { // (64 x 64 tiles, 64-steps: the slices are whole numbers of them)
+            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64, nvk::kNtSplit>, lds, device);
+            if (rc_lds != NVK_OK)
+                return rc_lds;
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<64, 64, 64, nvk::kNtSplit>), dim3((unsigned)wgs), dim3(256), lds, st, p);
         }
         else if (bm == 128) {
             int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<128, 128, 32>, lds, device);

@@ -111,11 +111,15 @@ def test_matmul_shapes_against_the_checker(B, D, N, nv, DA):
 @pytest.mark.parametrize("B,D,N", [(128, 5632, 2048), (100, 2052, 200), (256, 4096, 1000), (97, 1024, 65),
                                     (200, 8192, 64), (130, 516, 2048),
                                     # up to 16 rows over at most 128 column tiles (nvk_gemm_skinny_kernel<16, 1, 64, .., SPLIT>)
-                                    (16, 5632, 2048), (3, 2048, 2048), (9, 4100, 200), (16, 8192, 20), (5, 2052, 1028)])
+                                    (16, 5632, 2048), (3, 2048, 2048), (9, 4100, 200), (16, 8192, 20), (5, 2052, 1028),
+                                    # 33+ rows, at least 16 k-steps to a CU and tiles that would not fill the chip evenly: runs
+                                    # of k-steps across tile boundaries (nvk_gemm_nt_kernel<64, 64, 64, kNtStream>)
+                                    (64, 2048, 11264), (40, 4100, 6000), (130, 2052, 6000)])
 def test_split_k_tiles_against_the_checker_with_changing_inputs(B, D, N, nv, DA):
     """More rows than the weight-streaming kernel takes and too few 64 x 64 tiles for the chip -- or up to 16 rows and
     too few 16-column tiles: the contraction is cut into slices (nvk_gemm_nt_kernel<64, 64, 64, true>,
-    nvk_gemm_skinny_kernel<16, 1, 64, plain, false, true>), a workgroup per (tile, slice), partial tiles handed over
+    nvk_gemm_skinny_kernel<16, 1, 64, plain, false, true>), a workgroup per (tile, slice) -- or, stream-K, per run of
+    k-steps that crosses tile boundaries -- partial tiles handed over
     through an arrival counter and added in slice order by whoever comes last.  A wrong hand-off shows as stale or
     missing partials, so: three calls in a row with different activations, each against the checker; the same call
     twice gives the same bits (the order of the sums does not depend on who arrives last); and a row's result does
