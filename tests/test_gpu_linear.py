@@ -117,7 +117,7 @@ def test_matmul_shapes_against_the_checker(B, D, N, nv, DA):
                                     (64, 2048, 11264), (40, 4100, 6000), (130, 2052, 6000)])
 def test_split_k_tiles_against_the_checker_with_changing_inputs(B, D, N, nv, DA):
     """More rows than the weight-streaming kernel takes and too few 64 x 64 tiles for the chip -- or up to 16 rows and
-    too few 16-column tiles: the contraction is cut into slices (nvk_gemm_nt_kernel<64, 64, 64, true>,
+    too few 16-column tiles: the contraction is cut into slices (nvk_gemm_nt_kernel<64, 64, 64, kNtSplit>,
     nvk_gemm_skinny_kernel<16, 1, 64, plain, false, true>), a workgroup per (tile, slice) -- or, stream-K, per run of
     k-steps that crosses tile boundaries -- partial tiles handed over
     through an arrival counter and added in slice order by whoever comes last.  A wrong hand-off shows as stale or

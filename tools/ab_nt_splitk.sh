@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the split-K tiled kernel (nvk_gemm_nt_kernel<64, 64, 64, true>) against the kernels it replaces, on an
+# A/B of the split-K tiled kernel (nvk_gemm_nt_kernel<64, 64, 64, kNtSplit>) against the kernels it replaces, on an
 # -DNVK_LINEAR_ENV build: NVK_NT_SPLIT_MIN_ROWS=100000 switches it off.
 cd "$(dirname "$0")/.."
 export NVK_LIB_PATH=build/variants/linenv.so
