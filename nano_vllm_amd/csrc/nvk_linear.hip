@@ -91,6 +91,9 @@
 #ifndef NVK_NT_STREAM_MIN_ROWS
 #define NVK_NT_STREAM_MIN_ROWS 33 // from here a plain product runs nvk_gemm_nt_kernel<64, 64, 64, kNtStream> (stream-K) where ...
 #endif
+#ifndef NVK_NT_STREAM32_MIN_STEPS
+#define NVK_NT_STREAM32_MIN_STEPS 20 // 17-32 rows: stream-K over 32 x 128 tiles from this many 32-steps to a CU (0: never)
+#endif
 #ifndef NVK_NT_STREAM_MAX_TILES_PER_CU
 #define NVK_NT_STREAM_MAX_TILES_PER_CU 3 // ... its 64 x 64 tiles are fewer than this many per CU (more: plain tiles balance by themselves)
 #endif
@@ -266,11 +269,14 @@ __global__ void __launch_bounds__(256) nvk_rms_norm_kernel(float *__restrict__ o
 // summation order still does not depend on its row.  A workgroup's piece of a tile lies in slot 2 g (the tile its run
 // starts in) or 2 g + 1 (a later one) of p.part.
 enum { kNtPlain = 0, kNtSplit = 1, kNtStream = 2 };
-template <int BM, int BN, int BK, int MODE = kNtPlain>
+// WM: waves along the rows (2: the 2 x 2 layout above; 1: four waves side by side over a 32-row tile, for 17-32 rows).
+template <int BM, int BN, int BK, int MODE = kNtPlain, int WM = 2>
 __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams p)
 {
     constexpr bool SPLIT = MODE == kNtSplit, STREAM = MODE == kNtStream;
-    constexpr int TA = BM / 64, TB = BN / 64; // 32 x 32 MFMA tiles per wave along the rows / the columns
+    constexpr int WN = 4 / WM, SM = BM / WM, SN = BN / WN; // a wave's sub-tile: SM rows x SN columns
+    constexpr int TA = SM / 32, TB = SN / 32;              // 32 x 32 MFMA tiles per wave along the rows / the columns
+    static_assert((WM == 1 || WM == 2) && SM % 32 == 0 && SN % 32 == 0 && TA >= 1 && TB >= 1, "wave layout");
     constexpr int kGemmBK = BK, kGemmLds = BK + 4, KV = BK / 32; // KV: float4 per thread per tile row pass
     extern __shared__ __attribute__((aligned(16))) float s_mem[]; // [2][BM + BN][kGemmLds]
     __shared__ int s_last;
@@ -314,7 +320,7 @@ __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     const int lr = tid >> 3, lc = (tid & 7) * 4; // this thread's (row, first k) inside a 32-row pass of a tile
 
     const float *arow[BM / 32], *wrow[BN / 32];
@@ -373,8 +379,8 @@ __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams 
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, ACC, 0, 0, 0);                                                \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, ACC, 0, 0, 0);
     auto multiply = [&](int buf) {
-        const float *sa = s_mem + buf * (BM + BN) * kGemmLds + (wm * (BM / 2) + j) * kGemmLds + 4 * half;
-        const float *sb = s_mem + buf * (BM + BN) * kGemmLds + (BM + wn * (BN / 2) + j) * kGemmLds + 4 * half;
+        const float *sa = s_mem + buf * (BM + BN) * kGemmLds + (wm * SM + j) * kGemmLds + 4 * half;
+        const float *sb = s_mem + buf * (BM + BN) * kGemmLds + (BM + wn * SN + j) * kGemmLds + 4 * half;
         // operands of chunk c + 1 are read from LDS while chunk c is multiplied
         float4 av[2][TA], bv[2][TB];
         auto   operands = [&](int slot, int c) {
@@ -503,10 +509,10 @@ __global__ void __launch_bounds__(256, 2) nvk_gemm_nt_kernel(const LinearParams 
         for (int a = 0; a < TA; a++)
 #pragma unroll
             for (int b = 0; b < TB; b++) {
-                const int col = n0 + wn * (BN / 2) + 32 * b + j;
+                const int col = n0 + wn * SN + 32 * b + j;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int row = m0 + wm * (BM / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int row = m0 + wm * SM + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (row < p.m && col < sg.n)
                         sg.out[(int64_t)row * sg.ldo + col] = acc[a][b][r];
                 }
@@ -1276,10 +1282,10 @@ int cu_count_of(int device)
 // more than 64 KiB of dynamic LDS needs the attribute, once per device and kernel
 int opt_in_lds(const void *kernel, size_t lds_bytes, int device)
 {
-    static const void          *done[64][16];
+    static const void          *done[64][32];
     std::lock_guard<std::mutex> lock(g_first_use);
     const void                **row = done[device & 63];
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < 32; i++) {
         if (row[i] == kernel)
             return NVK_OK;
         if (!row[i]) {
@@ -1459,7 +1465,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             split = 1;
     }
     // ... or, for more rows than the weight-streaming kernel does well, the (tile, k-step) pairs dealt evenly over the CUs
-    int stream_steps = 0; // k-steps per workgroup of nvk_gemm_nt_kernel<64, 64, 64, kNtStream>; 0: not that kernel
+    int  stream_steps = 0; // k-steps per workgroup of nvk_gemm_nt_kernel<64, 64, 64, kNtStream>; 0: not that kernel
+    bool stream32     = false; // ... of nvk_gemm_nt_kernel<32, 128, 32, kNtStream, 1>
     {
         int stream_min_rows = NVK_NT_STREAM_MIN_ROWS, stream_fill = NVK_NT_STREAM_FILL, stream_min_steps = 16;
         bool stream_always = false;
@@ -1492,6 +1499,32 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             SplitWorkspace ws;
             if (per >= 2 && split_workspace(device, cus, st, (size_t)2 * per_row * m64 * 64 * 64, (size_t)t64, &ws)) {
                 stream_steps = (int)per;
+                split        = 1;
+                p.ksplit = (int)per_row, p.kslice = stream_steps, p.part = ws.part, p.arrive = ws.arrive;
+            }
+        }
+        // 17-32 rows: the same over 32 x 128 tiles in 32-steps (four waves side by side), where the weight-streaming kernel
+        // would run two 16-row tiles per weight tile (4096 -> 6144: 22 us at 16 rows, 33.6 at 17-32): 2048 -> 5632 x 2 at 32
+        // rows 34.7 -> 26.9 us, 4096 -> 6144 33.6 -> 29.2; smaller products lose (5632 -> 2048: 16.8 -> 23.2) and stay
+        int stream32_min_steps = NVK_NT_STREAM32_MIN_STEPS;
+#ifdef NVK_LINEAR_ENV // A/B build
+        if (const char *e = getenv("NVK_NT_STREAM32_MIN_STEPS"))
+            stream32_min_steps = atoi(e);
+#endif
+        long long n128 = 0;
+        for (int s = 0; s < nseg; s++)
+            n128 += (n[s] + 127) / 128;
+        const long long row_steps32 = n128 * ((in_dim + 31) / 32);
+        if (stream_steps == 0 && !glu && !rope && !link && batch > 16 && batch <= 32 && batch > NVK_GEMV_MAX_ROWS
+            && stream32_min_steps > 0 && row_steps32 >= (long long)stream32_min_steps * cus && row_steps32 < (1LL << 24)
+            && n128 <= (long long)kSplitCounters) {
+            long long       per_row = std::min<long long>((long long)stream_fill * cus, row_steps32);
+            const long long per     = (row_steps32 + per_row - 1) / per_row;
+            per_row                 = (row_steps32 + per - 1) / per;
+            SplitWorkspace ws;
+            if (per >= 2 && split_workspace(device, cus, st, (size_t)2 * per_row * 32 * 128, (size_t)n128, &ws)) {
+                stream_steps = (int)per;
+                stream32     = true;
                 split        = 1;
                 p.ksplit = (int)per_row, p.kslice = stream_steps, p.part = ws.part, p.arrive = ws.arrive;
             }
@@ -1540,6 +1573,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         // four times higher LDS and L2 traffic per flop
         if (split > 1 || stream_steps > 0 || NVK_GEMM_FORCE_TILE == 64 || (NVK_GEMM_FORCE_TILE == 0 && t128 < 6LL * cus))
             bm = bn = 64;
+        if (stream32)
+            bm = 32, bn = 128;
     }
     else
         bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (t16 ? 16 : 32);
@@ -1725,7 +1760,15 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             return nvk::fail(NVK_ERR_INVALID_ARG, "%s: %lld workgroups exceed the grid", who, wgs);
         const int    bk  = bm == 128 ? 32 : (batch <= 256 || split > 1 || stream_steps > 0 ? 64 : 32); // 64 x 64: fewer barriers while waves are few
         const size_t lds = (size_t)2 * (bm + bn) * (bk + 4) * sizeof(float);
-        if (stream_steps > 0) { // (64 x 64 tiles, 64-steps)
+        if (stream32) { // (32 x 128 tiles, 32-steps)
+            const size_t    lds32 = (size_t)2 * (32 + 128) * (32 + 4) * sizeof(float);
+            const long long grid  = (long long)p.ksplit * p.m_tiles;
+            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<32, 128, 32, nvk::kNtStream, 1>, lds32, device);
+            if (rc_lds != NVK_OK)
+                return rc_lds;
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<32, 128, 32, nvk::kNtStream, 1>), dim3((unsigned)grid), dim3(256), lds32, st, p);
+        }
+        else if (stream_steps > 0) { // (64 x 64 tiles, 64-steps)
             const long long grid = (long long)p.ksplit * p.m_tiles;
             int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<64, 64, 64, nvk::kNtStream>, lds, device);
             if (rc_lds != NVK_OK)
