@@ -91,6 +91,17 @@
 #ifndef NVK_NT_STREAM_MIN_ROWS
 #define NVK_NT_STREAM_MIN_ROWS 33 // from here a plain product runs nvk_gemm_nt_kernel<64, 64, 64, kNtStream> (stream-K) where ...
 #endif
+#ifdef NVK_LINEAR_ENV
+#define NVK_LINEAR_ENV_ON 1
+#else
+#define NVK_LINEAR_ENV_ON 0
+#endif
+#ifndef NVK_NT_STREAM128_MIN_ROWS
+#define NVK_NT_STREAM128_MIN_ROWS 100000 // from here: stream-K over 128 x 128 tiles where those are fewer than six to a CU (measured: off)
+#endif
+#ifndef NVK_NT_STREAM128_FILL
+#define NVK_NT_STREAM128_FILL 1 // workgroups per CU of that launch
+#endif
 #ifndef NVK_NT_STREAM32_MIN_STEPS
 #define NVK_NT_STREAM32_MIN_STEPS 20 // 17-32 rows: stream-K over 32 x 128 tiles from this many 32-steps to a CU (0: never)
 #endif
@@ -1332,7 +1343,8 @@ bool split_workspace(int device, int cus, hipStream_t st, size_t floats, size_t 
             (void)hipGetLastError();
             return false;
         }
-        const size_t nf = (size_t)4 * cus * 64 * 64, nc = kSplitCounters; // (stream-K: two pieces per workgroup, two workgroups per CU)
+        // (stream-K: two pieces per workgroup, two workgroups per CU; twice that for the 128 x 128 form when an A/B build turns it on)
+        const size_t nf = (size_t)(NVK_NT_STREAM128_MIN_ROWS < 100000 || NVK_LINEAR_ENV_ON ? 8 : 4) * cus * 64 * 64, nc = kSplitCounters;
         float       *pf = nullptr;
         int         *pc = nullptr;
         if (hipMalloc(&pf, nf * sizeof(float)) != hipSuccess || hipMalloc(&pc, nc * sizeof(int)) != hipSuccess
@@ -1467,6 +1479,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
     // ... or, for more rows than the weight-streaming kernel does well, the (tile, k-step) pairs dealt evenly over the CUs
     int  stream_steps = 0; // k-steps per workgroup of nvk_gemm_nt_kernel<64, 64, 64, kNtStream>; 0: not that kernel
     bool stream32     = false; // ... of nvk_gemm_nt_kernel<32, 128, 32, kNtStream, 1>
+    bool stream128    = false; // ... of nvk_gemm_nt_kernel<128, 128, 32, kNtStream>
     {
         int stream_min_rows = NVK_NT_STREAM_MIN_ROWS, stream_fill = NVK_NT_STREAM_FILL, stream_min_steps = 16;
         bool stream_always = false;
@@ -1529,6 +1542,38 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
                 p.ksplit = (int)per_row, p.kslice = stream_steps, p.part = ws.part, p.arrive = ws.arrive;
             }
         }
+        // many rows, yet fewer 128 x 128 tiles than fill the chip a few times over (512 rows x 6144 columns: 192, 0.75 to a
+        // CU; as 64 x 64 tiles 768, three rounds of which the last is half empty): stream-K over the 128 x 128 tiles.
+        // Built, parity green, NOT on: 2048 -> 5632 x 2 at 384 rows 207 -> 189 us and 4096 -> 6144 at 768 rows 394 -> 373, but
+        // 4096 -> 6144 at 512 rows 240 -> 229 on one box and 244 -> 247 on the next, nothing at 1024 rows
+        // (profiles/r03_nt_streamk.log) -- not worth 16 MiB more per stream
+        int stream128_min_rows = NVK_NT_STREAM128_MIN_ROWS;
+#ifdef NVK_LINEAR_ENV // A/B build
+        if (const char *e = getenv("NVK_NT_STREAM128_MIN_ROWS"))
+            stream128_min_rows = atoi(e);
+#endif
+        long long       c128 = 0; // (n128 above: column tiles of 128)
+        for (int s = 0; s < nseg; s++)
+            c128 += (n[s] + 127) / 128;
+        const int       m128        = (batch + 127) / 128;
+        const long long row_steps128 = c128 * ((in_dim + 31) / 32);
+        if (stream_steps == 0 && !glu && !rope && !link && batch >= stream128_min_rows && NVK_GEMM_FORCE_TILE != 64
+            && c128 * m128 < 6LL * cus && c128 * m128 <= (long long)kSplitCounters && row_steps128 * m128 >= 32LL * cus
+            && row_steps128 < (1LL << 24)) {
+            long long per_row = std::max<long long>(1, (long long)NVK_NT_STREAM128_FILL * cus / m128);
+            if (m128 > 1)
+                per_row = std::max<long long>(8, per_row / 8 * 8);
+            per_row = std::min(per_row, row_steps128);
+            const long long per = (row_steps128 + per_row - 1) / per_row;
+            per_row             = (row_steps128 + per - 1) / per;
+            SplitWorkspace ws;
+            if (per >= 2 && split_workspace(device, cus, st, (size_t)2 * per_row * m128 * 128 * 128, (size_t)(c128 * m128), &ws)) {
+                stream_steps = (int)per;
+                stream128    = true;
+                split        = 1;
+                p.ksplit = (int)per_row, p.kslice = stream_steps, p.part = ws.part, p.arrive = ws.arrive;
+            }
+        }
     }
     const bool skinny = batch <= NVK_SKINNY_MAX_ROWS && split == 1 && stream_steps == 0;
     p.a = in, p.m = batch, p.k = in_dim, p.lda = in_dim;
@@ -1575,6 +1620,8 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             bm = bn = 64;
         if (stream32)
             bm = 32, bn = 128;
+        if (stream128)
+            bm = bn = 128;
     }
     else
         bn = gemv ? (batch <= 2 ? NVK_GEMV_COLS : 32) : (t16 ? 16 : 32);
@@ -1767,6 +1814,14 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             if (rc_lds != NVK_OK)
                 return rc_lds;
             hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<32, 128, 32, nvk::kNtStream, 1>), dim3((unsigned)grid), dim3(256), lds32, st, p);
+        }
+        else if (stream128) { // (128 x 128 tiles, 32-steps)
+            const size_t    lds128 = (size_t)2 * (128 + 128) * (32 + 4) * sizeof(float);
+            const long long grid   = (long long)p.ksplit * p.m_tiles;
+            int rc_lds = opt_in_lds((const void *)nvk::nvk_gemm_nt_kernel<128, 128, 32, nvk::kNtStream>, lds128, device);
+            if (rc_lds != NVK_OK)
+                return rc_lds;
+            hipLaunchKernelGGL((nvk::nvk_gemm_nt_kernel<128, 128, 32, nvk::kNtStream>), dim3((unsigned)grid), dim3(256), lds128, st, p);
         }
         else if (stream_steps > 0) { // (64 x 64 tiles, 64-steps)
             const long long grid = (long long)p.ksplit * p.m_tiles;

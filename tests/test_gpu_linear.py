@@ -116,7 +116,7 @@ def test_matmul_shapes_against_the_checker(B, D, N, nv, DA):
                                     # of k-steps across tile boundaries (nvk_gemm_nt_kernel<64, 64, 64, kNtStream>)
                                     (64, 2048, 11264), (40, 4100, 6000), (130, 2052, 6000),
                                     # 17-32 rows of a large product: the same over 32 x 128 tiles (<32, 128, 32, kNtStream, 1>)
-                                    (24, 2052, 11000), (32, 4096, 6144)])
+                                    (24, 2052, 11000), (32, 4096, 6144), (400, 2052, 5000)])
 def test_split_k_tiles_against_the_checker_with_changing_inputs(B, D, N, nv, DA):
     """More rows than the weight-streaming kernel takes and too few 64 x 64 tiles for the chip -- or up to 16 rows and
     too few 16-column tiles: the contraction is cut into slices (nvk_gemm_nt_kernel<64, 64, 64, kNtSplit>,
