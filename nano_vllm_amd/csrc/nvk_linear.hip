@@ -1500,6 +1500,10 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
         // a tenth of the chip idle or more -- plain tiles always do below 3 per CU, the cut tiles where their slices do
         // not fill the slots
         const bool cut_fills = split > 1 && t64 * split * 10 >= 2LL * cus * 9;
+        // (one row tile with 8-16 steps to a CU over at least 32 column tiles: one workgroup per CU -- 5632 -> 2048 at 64 rows
+        //  29.7 -> 25.9 us, 2048 -> 4096 27.0 -> 20.2; with fewer column tiles too many runs share a tile: 8192 -> 1024 loses)
+        if (m64 == 1 && n64 >= 32 && row_steps >= 8LL * cus && row_steps < 16LL * cus && stream_min_steps == 16)
+            stream_min_steps = 8, stream_fill = 1;
         if (!glu && !rope && !link && batch >= stream_min_rows && batch > NVK_GEMV_MAX_ROWS && NVK_GEMM_FORCE_TILE != 128
             && (t64 < (long long)NVK_NT_STREAM_MAX_TILES_PER_CU * cus || stream_always) && t64 <= (long long)kSplitCounters
             && row_steps * m64 >= (long long)stream_min_steps * cus && row_steps < (1LL << 24) && (!cut_fills || stream_always)) {
