@@ -449,7 +449,7 @@ def projection_rows(nv, torch, dev, ev, args):
                         "algorithmic_bytes": wbytes, "GBps": round(wbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                         "frac": round(wbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
         else:
-            row.update({"bound": "mfma", "kernel": "nvk::nvk_gemm_nt_kernel<64, 64, 32, 0>", "algorithmic_flops": flops,
+            row.update({"bound": "mfma", "kernel": "nvk::nvk_gemm_nt_kernel<64, 64, 32, 0, 2>", "algorithmic_flops": flops,
                         "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                         "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)})
         res[f"qkv_{rows}row" if rows == 1 else f"qkv_{rows}rows"] = row
