@@ -273,3 +273,36 @@ def test_argument_errors(nv, DA):
     with pytest.raises(nv.NvkError):
         nv.qkv_project_device(a, a, a, a, None, a, a, a, a, 4, 8, 8, 8)  # rms weight given, no xb scratch
     nv.batch_matmul_device(a, a, a, 0, 8, 4)  # empty batch: nothing to do
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_runs_of_k_steps_over_several_segments(seed, nv, DA):
+    """Stream-K launches of two and three weight segments (w_gate | w_up, q | k | v without the norm) at 17-200 rows, ragged
+    in every dimension: the runs cross tile AND segment boundaries.  Every output against the checker; the same call
+    twice gives the same bits."""
+    d = [int(v) for v in np.random.default_rng(4400 + seed).integers(0, 1 << 30, 8)]
+    B = [17, 24, 32, 33, 48, 64, 100, 200][seed]
+    D = 4 * (500 + d[0] % 600)          # 2000 .. 4396, a multiple of 4 and mostly not of 64
+    NA = 4 * (900 + d[1] % 900)         # 3600 .. 7196
+    NB = 4 * (200 + d[2] % 400)
+    x = uniform(4500 + seed, 0, B * D).reshape(B, D)
+    sc = np.float32(1.0 / np.sqrt(D))
+    wa = (uniform(4510 + seed, 0, NA * D) * sc).reshape(NA, D)
+    wb = (uniform(4520 + seed, 0, NB * D) * sc).reshape(NB, D)
+    rows = sorted({0, B // 2, B - 1})
+    dx, dwa, dwb = DA(x), DA(wa), DA(wb)
+    oa, ob = DA(np.full((B, NA), np.nan, np.float32)), DA(np.full((B, NB), np.nan, np.float32))
+    nv.batch_matmul2_device(oa, ob, dx, dwa, dwb, B, D, NA, NB)
+    ga, gb = oa.numpy(), ob.numpy()
+    assert np.isfinite(ga).all() and np.isfinite(gb).all()
+    assert close(ga[rows], ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x[rows], wa))
+    assert close(gb[rows], ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x[rows], wb))
+    nv.batch_matmul2_device(oa, ob, dx, dwa, dwb, B, D, NA, NB)
+    assert np.array_equal(oa.numpy(), ga) and np.array_equal(ob.numpy(), gb)
+    # three segments: q | k | v of the same activations, no norm
+    q, k, v = (DA(np.full((B, n), np.nan, np.float32)) for n in (NA, NB, NB))
+    nv.qkv_project_device(q, k, v, dx, None, None, dwa, dwb, dwb, B, D, NA, NB)
+    assert close(q.numpy()[rows], ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x[rows], wa))
+    assert close(k.numpy()[rows], ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x[rows], wb))
+    assert close(v.numpy()[rows], ol.batch_matmul(ol.ORACLE.oracle_batch_matmul, x[rows], wb))
+    # (k and v have the same weights here but sit at different places of the run order: other cuts, other last bits)
