@@ -82,6 +82,9 @@
 #ifndef NVK_SKINNY16_WIDE
 #define NVK_SKINNY16_WIDE 1 // 17-64 rows over few columns: 16 x 16 tiles, one workgroup per row tile (0: 32 x 32 tiles)
 #endif
+#ifndef NVK_SKINNY16_BALANCE_PCT
+#define NVK_SKINNY16_BALANCE_PCT 25 // the balanced 16-row kernel where 16-column tiles leave the busiest CU this much above the mean
+#endif
 #ifndef NVK_SKINNY16_SPLIT
 #define NVK_SKINNY16_SPLIT 1 // up to 16 rows over at most half as many 16-column tiles as CUs: the contraction cut into slices
 #endif
@@ -1640,7 +1643,7 @@ int launch_linear(const float *in, int batch, int in_dim, const float *const *w,
             t16s += (n[s] + 15) / 16;
         t16s *= (batch + 15) / 16;
         const long long rounds = (t16s + cus - 1) / cus;
-        balanced = balanced && t16s > cus && rounds * cus * 4 >= t16s * 5;
+        balanced = balanced && t16s > cus && rounds * cus * 100 >= t16s * (100 + NVK_SKINNY16_BALANCE_PCT);
     }
     for (int s = 0; s < nseg; s++)
         balanced = balanced && n[s] % 4 == 0; // (its workgroups own whole float4s of a row)
