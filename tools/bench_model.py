@@ -33,7 +33,7 @@ ap.add_argument("--chunk", type=int, default=2048, help="prompt tokens fed per r
 args = ap.parse_args()
 D, Hd, L, H, KV, V, S = PRESETS[args.preset]
 hd = D // H
-assert args.ctx + args.steps + 1 <= S, "context + steps exceed the preset's max_seq_len"
+assert args.ctx + args.steps + 4 <= S, "context + steps exceed the preset's max_seq_len"
 path = f"/tmp/nvk_bench_{args.preset}.bin"
 sizes = [V * D, L * D, L * D * H * hd, L * D * KV * hd, L * D * KV * hd, L * H * hd * D, L * D, L * D * Hd, L * Hd * D,
          L * D * Hd, D]
@@ -74,7 +74,8 @@ with nv.LlamaModel(path, bs, blocks, max_seqs=args.seqs) as m:
         nxt, _ = m.step_chunks(ids, [rng.integers(3, V, size=c).tolist() for _ in ids])
         fed += c
     t_prefill = time.perf_counter() - t0
-    nxt, _ = m.step(ids, nxt.tolist())  # warm-up decode step
+    for _ in range(4):  # warm-up decode steps (the graph is recorded during these)
+        nxt, _ = m.step(ids, nxt.tolist())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nxt, _ = m.step(ids, nxt.tolist())
