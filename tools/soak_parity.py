@@ -1,0 +1,48 @@
+"""Seeds beyond the ones `pytest -m gpu` runs, for the differential sweeps of tests/ (random head geometry, block size,
+ragged lengths, fragmented tables; decode in every mode, the in-kernel merge and plan-free launches, skewed long chunks,
+chunked prefill), each against the CPU checker at the path's tolerance:
+    python tools/soak_parity.py --first 100 --minutes 8
+One line per sweep: seeds run, failures (with the seed and the assertion's first line).  Exit status 1 on any failure."""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--first", type=int, default=100, help="first seed (the tests run the seeds below 36)")
+ap.add_argument("--minutes", type=float, default=8.0)
+args = ap.parse_args()
+
+import test_gpu_attention as ta  # noqa: E402
+import test_gpu_fused_merge as tm  # noqa: E402
+import test_gpu_prefill as tp  # noqa: E402
+
+SWEEPS = [
+    ("decode: auto / single pass / split-K", ta.test_random_geometry_batches_against_checker),
+    ("decode: in-kernel merge, plan-free", tm.test_in_kernel_merge_and_planless_decode_on_random_geometries),
+    ("decode: skewed long chunks", tm.test_skewed_chunks_on_random_long_batches),
+    ("prefill: paged chunks", tp.test_random_geometry_prefill_against_checker),
+]
+budget = args.minutes * 60 / len(SWEEPS)
+bad = 0
+for name, fn in SWEEPS:
+    t0, seed, fails = time.perf_counter(), args.first, []
+    said = t0
+    while time.perf_counter() - t0 < budget:
+        if time.perf_counter() - said > 30:  # (a run that writes nothing for minutes is taken to be hung)
+            print(f"  ... {name}: at seed {seed}", flush=True)
+            said = time.perf_counter()
+        try:
+            fn(seed)
+        except Exception as e:  # an assertion, or an error code from the library
+            fails.append((seed, (str(e).splitlines() or [type(e).__name__])[0][:200]))
+            traceback.print_exc(limit=1)
+        seed += 1
+    print(f"{name:40s} seeds {args.first}..{seed - 1} ({seed - args.first} cases, {time.perf_counter() - t0:.0f} s): "
+          f"{len(fails)} failed {fails if fails else ''}", flush=True)
+    bad += len(fails)
+sys.exit(1 if bad else 0)
