@@ -83,7 +83,109 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def model_case(seed):
+    """A random llama2.c checkpoint (head geometry, layers, widths, vocabulary, block size, shared or own classifier)
+    through the device-resident model: 1-6 requests with different prompts, joining at different steps, prompts fed
+    in chunks, greedy decode.  Every logits row against the checker's LlamaModel::forward of that request alone, fed
+    the tokens the device chose (2e-3 + 1e-4 |ref| + 1e-4 max |ref|: the model-level bar of tests/test_gpu_model_stream.py
+    plus a term in the row's scale), and the
+    argmax wherever the checker's first two logits are further apart than that bar."""
+    import ctypes as C
+    import tempfile
+
+    import oracle_lib as ol
+    from golden_defs import write_checkpoint
+
+    rng = np.random.default_rng(seed)
+    while True:
+        hd = int(rng.choice([4, 8, 16, 20, 32, 48, 64, 128]))
+        KV = int(rng.choice([1, 2, 3, 4, 6, 8]))
+        H = KV * int(rng.choice([1, 2, 3, 4, 8]))
+        if H * hd <= 768:
+            break
+    bs = int(rng.choice([4, 8, 16, 32]))
+    n_req = int(rng.integers(1, 7))
+    max_seq = int(rng.integers(48, 129))
+    spec = dict(dim=H * hd, hidden_dim=4 * int(rng.integers(8, 300)), n_layers=int(rng.integers(1, 5)), n_heads=H,
+                n_kv_heads=KV, vocab_size=int(rng.integers(40, 600)), max_seq_len=max_seq, block_size=bs,
+                num_blocks=n_req * ((max_seq + bs - 1) // bs) + int(rng.integers(0, 4)), weight_seed=1000 + seed,
+                weight_gain=0.0, shared=bool(rng.integers(0, 2)))
+    # (the fixtures' conditioning: 0.35 at dim 96, 0.30 at dim 288; wider models with such weights saturate the softmax
+    #  and the logits' differences stop being rounding)
+    spec["weight_gain"] = float(min(0.35, 5.0 / np.sqrt(spec["dim"])))
+    gen = int(rng.integers(4, 14))
+    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=int(rng.integers(0, max_seq - gen - 2))).tolist()
+               for _ in range(n_req)]
+    join = [0] + [int(rng.integers(0, 5)) for _ in range(n_req - 1)]
+    chunk = int(rng.choice([1, 3, 7, 16, 200]))  # prompt tokens fed per step
+    what = f"seed {seed}: {spec} prompts {[len(q) for q in prompts]} join {join} chunk {chunk}"
+    V = spec["vocab_size"]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.bin")
+        write_checkpoint(path, spec)
+        # (the checker's model, like the reference's, takes every layer's blocks from one manager)
+        oracles = [ol.ORACLE.oracle_model_create(path.encode(), bs, spec["n_layers"] * ((max_seq + bs - 1) // bs + 1))
+                   for _ in range(n_req)]
+        assert all(oracles), what
+        o_pos = [0] * n_req
+        want = np.empty(V, np.float32)
+
+        def oracle_feed(r, tokens):  # returns the logits behind the last token
+            for i, t in enumerate(tokens):
+                last = i == len(tokens) - 1
+                rc = ol.ORACLE.oracle_model_forward(oracles[r], int(t), o_pos[r], want.ctypes.data_as(C.c_void_p) if last else None)
+                assert rc == 0, f"{what}: checker refused token {o_pos[r]} of request {r}"
+                o_pos[r] += 1
+            return want
+
+        try:
+            with nv.LlamaModel(path, bs, spec["num_blocks"], max_seqs=n_req) as m:
+                fed = [0] * n_req          # prompt tokens already given
+                out = [[] for _ in range(n_req)]
+                joined = [False] * n_req
+                for step in range(400):
+                    ids, chunks = [], []
+                    for r in range(n_req):
+                        if join[r] > step or len(out[r]) >= gen:
+                            continue
+                        if not joined[r]:
+                            m.add_request(10 + r)
+                            joined[r] = True
+                        if fed[r] < len(prompts[r]):
+                            piece = prompts[r][fed[r]:fed[r] + chunk]
+                            fed[r] += len(piece)
+                        else:
+                            piece = [out[r][-1]]
+                        ids.append(r), chunks.append(piece)
+                    if not ids:
+                        if all(len(o) >= gen for o in out):
+                            break
+                        continue
+                    nxt, logits = m.step_chunks([10 + r for r in ids], chunks, True)
+                    for row, (r, piece) in enumerate(zip(ids, chunks)):
+                        ref = oracle_feed(r, piece)
+                        got = logits[row]
+                        err = np.abs(got - ref)
+                        # (the fixtures' logits are O(5); these reach 50 at dim 768, so the bar gets a term in the row's scale)
+                        bar = 2e-3 + 1e-4 * np.abs(ref) + 1e-4 * float(np.abs(ref).max())
+                        assert np.isfinite(got).all() and (err <= bar).all(), \
+                            f"{what}: step {step} request {r} at {o_pos[r]} tokens: max err {err.max():.3e}, largest logit {np.abs(ref).max():.1f}"
+                        top = np.sort(ref)[-2:]
+                        if fed[r] >= len(prompts[r]):  # the token behind a finished prompt, or behind a decode token
+                            if top[1] - top[0] > 2 * float(bar.max()):
+                                assert int(nxt[row]) == int(np.argmax(ref)), f"{what}: step {step} request {r}: argmax"
+                            out[r].append(int(nxt[row]))
+                            if len(out[r]) >= gen:
+                                m.finish_request(10 + r)
+                assert all(len(o) >= gen for o in out), what
+                assert m.free_blocks == spec["num_blocks"], what
+        finally:
+            for o in oracles:
+                ol.ORACLE.oracle_model_destroy(o)
+
+
 SWEEPS = [
+    ("model: random checkpoints, batches", model_case),
     ("projections: every entry point", projection_case),
     ("decode: auto / single pass / split-K", ta.test_random_geometry_batches_against_checker),
     ("decode: in-kernel merge, plan-free", tm.test_in_kernel_merge_and_planless_decode_on_random_geometries),
@@ -103,7 +205,7 @@ for name, fn in SWEEPS:
         try:
             fn(seed)
         except Exception as e:  # an assertion, or an error code from the library
-            fails.append((seed, (str(e).splitlines() or [type(e).__name__])[0][:200]))
+            fails.append((seed, (str(e).splitlines() or [type(e).__name__])[0][-160:]))
             traceback.print_exc(limit=1)
         seed += 1
     print(f"{name:40s} seeds {args.first}..{seed - 1} ({seed - args.first} cases, {time.perf_counter() - t0:.0f} s): "
