@@ -83,6 +83,42 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def noalloc_case(seed):
+    """nvk_decode_device_noalloc (the entry point that allocates nothing) against nvk_decode_device, bit for bit, on a
+    random geometry / batch / mode; sizes past its stated maximum must be refused with an error, nothing else."""
+    from nano_vllm_amd import workloads as wl
+
+    rng = np.random.default_rng(seed)
+    KV = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 16]))
+    H = KV * int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 16]))
+    hd = int(rng.choice([4, 16, 20, 48, 64, 80, 96, 128, 132, 192, 256]))
+    bs = int(rng.choice([1, 4, 8, 12, 16, 32]))
+    n = int(rng.integers(1, 12))
+    top = int(rng.choice([40, 300, 1500, 5000]))
+    ctx = rng.integers(0, top + 1, size=n).astype(np.int32)
+    ctx[int(rng.integers(0, n))] = top  # (a pool needs a block)
+    g = wl.Geometry(H, KV, hd, bs)
+    work = wl.fragmented_workload(f"na{seed}", ctx, g, slack=0.3, perm_seed=seed)
+    q = work.q()
+    flags, chunk = [(nv.AUTO, 0), (nv.SPLIT_K, int(rng.choice([8, 24, 64, 200, 512]))),
+                    (nv.SPLIT_K | nv.MERGE_SEPARATE, int(rng.choice([24, 64, 256]))),
+                    (nv.SPLIT_K | nv.NO_PLAN, int(rng.choice([64, 128, 512]))), (nv.SINGLE_PASS, 0)][int(rng.integers(0, 5))]
+    what = f"seed {seed}: H{H} KV{KV} hd{hd} bs{bs} ctx{ctx.tolist()} flags={flags} chunk={chunk}"
+    with nv.PagedKVPool(1, work.num_blocks, bs, KV, hd) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        qd, td, cd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(work.ctx_lens)
+        o1, o2 = DeviceArray(np.full_like(q, np.nan)), DeviceArray(np.full_like(q, np.nan))
+        try:
+            nv.decode_device_noalloc(pool, 0, n, H, qd, td, work.max_blocks, cd, work.max_ctx, o1, flags, chunk)
+        except nv.NvkError as e:
+            assert "the static array holds" in str(e), f"{what}: {e}"
+            return "refused (more scratch than the static array holds)"
+        nv.decode_device(pool, 0, n, H, qd, td, work.max_blocks, cd, work.max_ctx, o2, flags, chunk)
+        pool.synchronize()
+        a, b = o1.numpy(), o2.numpy()
+        assert np.isfinite(b).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: bits differ"
+
+
 def model_case(seed):
     """A random llama2.c checkpoint (head geometry, layers, widths, vocabulary, block size, shared or own classifier)
     through the device-resident model: 1-6 requests with different prompts, joining at different steps, prompts fed
@@ -186,6 +222,7 @@ def model_case(seed):
 
 SWEEPS = [
     ("model: random checkpoints, batches", model_case),
+    ("decode: the no-alloc entry point", noalloc_case),
     ("projections: every entry point", projection_case),
     ("decode: auto / single pass / split-K", ta.test_random_geometry_batches_against_checker),
     ("decode: in-kernel merge, plan-free", tm.test_in_kernel_merge_and_planless_decode_on_random_geometries),
@@ -196,19 +233,21 @@ SWEEPS = [sw for sw in SWEEPS if args.only in sw[0]]
 budget = args.minutes * 60 / len(SWEEPS)
 bad = 0
 for name, fn in SWEEPS:
-    t0, seed, fails = time.perf_counter(), args.first, []
+    t0, seed, fails, notes = time.perf_counter(), args.first, [], {}
     said = t0
     while time.perf_counter() - t0 < budget:
         if time.perf_counter() - said > 30:  # (a run that writes nothing for minutes is taken to be hung)
             print(f"  ... {name}: at seed {seed}", flush=True)
             said = time.perf_counter()
         try:
-            fn(seed)
+            note = fn(seed)
+            if note:
+                notes[note] = notes.get(note, 0) + 1
         except Exception as e:  # an assertion, or an error code from the library
             fails.append((seed, (str(e).splitlines() or [type(e).__name__])[0][-160:]))
             traceback.print_exc(limit=1)
         seed += 1
     print(f"{name:40s} seeds {args.first}..{seed - 1} ({seed - args.first} cases, {time.perf_counter() - t0:.0f} s): "
-          f"{len(fails)} failed {fails if fails else ''}", flush=True)
+          f"{len(fails)} failed {fails if fails else ''}{' ' + str(notes) if notes else ''}", flush=True)
     bad += len(fails)
 sys.exit(1 if bad else 0)
