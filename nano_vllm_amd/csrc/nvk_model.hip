@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "nvk_device_scope.h"
@@ -446,6 +448,15 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
     if (rows > 0x3fffffffLL)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: %lld rows in one step", rows);
     NVK_SCOPE(m->device);
+    // Several models may live on one device, each stepped by a thread of its own (nvk_model_group_* with a device named
+    // twice; two engines in one process).  While one of them RECORDS its step (stream capture, below), no other may be
+    // inside a step on that device: a first-use path there -- an allocation, a fill on the null stream, a device-wide
+    // wait -- invalidates the recording even in thread-local capture mode, and the runtime then leaves the recording
+    // stream unusable (every later call on it: "operation failed due to a previous error during capture").  Steps hold
+    // the device's gate shared; a recording holds it alone, for the microseconds it takes.
+    static std::shared_mutex            record_gate[64];
+    std::shared_mutex                  &gate_mutex = record_gate[m->device & 63];
+    std::shared_lock<std::shared_mutex> gate(gate_mutex);
     int         rc = reserve_rows(m, (int)rows);
     if (rc != NVK_OK)
         return rc;
@@ -598,6 +609,8 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
                 // record the body (nothing runs while capturing); any refusal -- a first-use allocation inside an entry
                 // point, say -- ends the capture and this step runs directly
                 hipGraph_t graph = nullptr;
+                gate.unlock();
+                std::unique_lock<std::shared_mutex> alone(gate_mutex); // (see the gate above)
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                     const int  rb = enqueue_body();
                     hipError_t ec = hipStreamEndCapture(st, &graph);
@@ -620,6 +633,8 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
                     if (graph)
                         (void)hipGraphDestroy(graph);
                 }
+                alone.unlock();
+                gate.lock();
             }
             if (m->graph_exec) {
                 if (hipGraphLaunch(m->graph_exec, st) == hipSuccess)

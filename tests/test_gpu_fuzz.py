@@ -1,0 +1,31 @@
+"""A few seeds of every random sweep of tests/fuzz_cases.py (tools/soak_parity.py runs the same generators for minutes:
+profiles/r03_soak_parity.log): random products through the projection entry points against float64, the no-alloc entry
+point bit for bit against nvk_decode_device, random llama2.c checkpoints through the device-resident model -- and through
+a group of models sharing device 0, where one member records its decode step as a graph while another is in a first-use
+path (an allocation, a device-wide wait); that used to invalidate the recording and leave the member's stream unusable
+-- against the checker's LlamaModel::forward (include/core/model.hpp:150-247)."""
+import pytest
+
+from fuzz_cases import model_case, noalloc_case, projection_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_products_through_the_projection_entry_points(seed):
+    projection_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_noalloc_entry_point_on_random_batches(seed):
+    noalloc_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_checkpoints_through_the_device_model(seed):
+    model_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(5000, 5040))
+def test_random_checkpoints_through_a_group_of_models_on_one_device(seed):
+    model_case(seed, group=True)

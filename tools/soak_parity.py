@@ -23,205 +23,11 @@ import test_gpu_attention as ta  # noqa: E402
 import test_gpu_fused_merge as tm  # noqa: E402
 import test_gpu_prefill as tp  # noqa: E402
 
-import numpy as np  # noqa: E402
-import nano_vllm_amd as nv  # noqa: E402
-from hipmem import DeviceArray  # noqa: E402
-
-
-def projection_case(seed):
-    """One random product through the C ABI's projection entry points (every kernel family and its thresholds are a
-    function of rows, columns, contraction and the number of products sharing the activations) against float64."""
-    rng = np.random.default_rng(seed)
-    B = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 32, 33, 48, 64, 65, 96, 97, 128, 129, 200, 256, 300, 512, 700])
-            if rng.random() < 0.7 else rng.integers(1, 600))
-    K = int(rng.choice([64, 256, 288, 768, 2048, 4096, 5632]) if rng.random() < 0.6 else 4 * rng.integers(1, 1500))
-    kind = int(rng.integers(0, 4))  # matmul, matmul2, swiglu_ffn, q|k|v (with or without the norm)
-    top = max(4, min(6000, int(3e9 / (B * K))))
-    dims = [int(rng.choice([32, 64, 256, 2048, 2560, 5632]) if rng.random() < 0.4 else rng.integers(1, top)) for _ in range(3)]
-    dims = [min(d, top) for d in dims]
-    x = (rng.random((B, K), dtype=np.float32) - 0.5)
-    mk = lambda n: ((rng.random((n, K), dtype=np.float32) - 0.5) / np.float32(np.sqrt(K) / 2))  # noqa: E731
-    xd = DeviceArray(x)
-    x64 = x.astype(np.float64)
-    what = f"seed {seed}: kind {kind}, {B} rows, {K} -> {dims}"
-
-    def close(got, want, tag):
-        err = np.abs(got.astype(np.float64) - want)
-        tol = 1e-4 + 1e-5 * np.abs(want)
-        assert np.isfinite(got).all() and (err <= tol).all(), f"{what} {tag}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
-
-    if kind == 0:
-        w = mk(dims[0])
-        o = DeviceArray(np.full((B, dims[0]), np.nan, np.float32))
-        nv.batch_matmul_device(o, xd, DeviceArray(w), B, K, dims[0])
-        close(o.numpy(), x64 @ w.astype(np.float64).T, "matmul")
-    elif kind == 1:
-        wa, wb = mk(dims[0]), mk(dims[1])
-        oa, ob = DeviceArray(np.full((B, dims[0]), np.nan, np.float32)), DeviceArray(np.full((B, dims[1]), np.nan, np.float32))
-        nv.batch_matmul2_device(oa, ob, xd, DeviceArray(wa), DeviceArray(wb), B, K, dims[0], dims[1])
-        close(oa.numpy(), x64 @ wa.astype(np.float64).T, "matmul2 a")
-        close(ob.numpy(), x64 @ wb.astype(np.float64).T, "matmul2 b")
-    elif kind == 2:
-        wg, wu = mk(dims[0]), mk(dims[0])
-        hb, hb2 = DeviceArray(np.full((B, dims[0]), np.nan, np.float32)), DeviceArray(np.zeros((B, dims[0]), np.float32))
-        nv.batch_swiglu_ffn_device(hb, hb2, xd, DeviceArray(wg), DeviceArray(wu), B, K, dims[0])
-        g = x64 @ wg.astype(np.float64).T
-        close(hb.numpy(), g / (1.0 + np.exp(-g)) * (x64 @ wu.astype(np.float64).T), "swiglu")
-    else:
-        qd, kvd = dims[0], dims[1]
-        wq, wk, wv = mk(qd), mk(kvd), mk(kvd)
-        normed = bool(rng.integers(0, 2))
-        gain = (1.0 + 0.1 * (rng.random(K, dtype=np.float32) - 0.5)).astype(np.float32)
-        q, k, v = (DeviceArray(np.full((B, n), np.nan, np.float32)) for n in (qd, kvd, kvd))
-        xb = DeviceArray(np.zeros((B, K), np.float32))
-        nv.qkv_project_device(q, k, v, xd, xb if normed else None, DeviceArray(gain) if normed else None, DeviceArray(wq),
-                              DeviceArray(wk), DeviceArray(wv), B, K, qd, kvd)
-        a = x64
-        if normed:
-            a = x64 / np.sqrt((x64 * x64).mean(axis=1, keepdims=True) + 1e-5) * gain.astype(np.float64)
-        for o, w, tag in ((q, wq, "q"), (k, wk, "k"), (v, wv, "v")):
-            close(o.numpy(), a @ w.astype(np.float64).T, tag)
-
-
-def noalloc_case(seed):
-    """nvk_decode_device_noalloc (the entry point that allocates nothing) against nvk_decode_device, bit for bit, on a
-    random geometry / batch / mode; sizes past its stated maximum must be refused with an error, nothing else."""
-    from nano_vllm_amd import workloads as wl
-
-    rng = np.random.default_rng(seed)
-    KV = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 16]))
-    H = KV * int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 16]))
-    hd = int(rng.choice([4, 16, 20, 48, 64, 80, 96, 128, 132, 192, 256]))
-    bs = int(rng.choice([1, 4, 8, 12, 16, 32]))
-    n = int(rng.integers(1, 12))
-    top = int(rng.choice([40, 300, 1500, 5000]))
-    ctx = rng.integers(0, top + 1, size=n).astype(np.int32)
-    ctx[int(rng.integers(0, n))] = top  # (a pool needs a block)
-    g = wl.Geometry(H, KV, hd, bs)
-    work = wl.fragmented_workload(f"na{seed}", ctx, g, slack=0.3, perm_seed=seed)
-    q = work.q()
-    flags, chunk = [(nv.AUTO, 0), (nv.SPLIT_K, int(rng.choice([8, 24, 64, 200, 512]))),
-                    (nv.SPLIT_K | nv.MERGE_SEPARATE, int(rng.choice([24, 64, 256]))),
-                    (nv.SPLIT_K | nv.NO_PLAN, int(rng.choice([64, 128, 512]))), (nv.SINGLE_PASS, 0)][int(rng.integers(0, 5))]
-    what = f"seed {seed}: H{H} KV{KV} hd{hd} bs{bs} ctx{ctx.tolist()} flags={flags} chunk={chunk}"
-    with nv.PagedKVPool(1, work.num_blocks, bs, KV, hd) as pool:
-        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
-        qd, td, cd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(work.ctx_lens)
-        o1, o2 = DeviceArray(np.full_like(q, np.nan)), DeviceArray(np.full_like(q, np.nan))
-        try:
-            nv.decode_device_noalloc(pool, 0, n, H, qd, td, work.max_blocks, cd, work.max_ctx, o1, flags, chunk)
-        except nv.NvkError as e:
-            assert "the static array holds" in str(e), f"{what}: {e}"
-            return "refused (more scratch than the static array holds)"
-        nv.decode_device(pool, 0, n, H, qd, td, work.max_blocks, cd, work.max_ctx, o2, flags, chunk)
-        pool.synchronize()
-        a, b = o1.numpy(), o2.numpy()
-        assert np.isfinite(b).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: bits differ"
-
-
-def model_case(seed):
-    """A random llama2.c checkpoint (head geometry, layers, widths, vocabulary, block size, shared or own classifier)
-    through the device-resident model: 1-6 requests with different prompts, joining at different steps, prompts fed
-    in chunks, greedy decode.  Every logits row against the checker's LlamaModel::forward of that request alone, fed
-    the tokens the device chose (2e-3 + 1e-4 |ref| + 1e-4 max |ref|: the model-level bar of tests/test_gpu_model_stream.py
-    plus a term in the row's scale), and the
-    argmax wherever the checker's first two logits are further apart than that bar."""
-    import ctypes as C
-    import tempfile
-
-    import oracle_lib as ol
-    from golden_defs import write_checkpoint
-
-    rng = np.random.default_rng(seed)
-    while True:
-        hd = int(rng.choice([4, 8, 16, 20, 32, 48, 64, 128]))
-        KV = int(rng.choice([1, 2, 3, 4, 6, 8]))
-        H = KV * int(rng.choice([1, 2, 3, 4, 8]))
-        if H * hd <= 768:
-            break
-    bs = int(rng.choice([4, 8, 16, 32]))
-    n_req = int(rng.integers(1, 7))
-    max_seq = int(rng.integers(48, 129))
-    spec = dict(dim=H * hd, hidden_dim=4 * int(rng.integers(8, 300)), n_layers=int(rng.integers(1, 5)), n_heads=H,
-                n_kv_heads=KV, vocab_size=int(rng.integers(40, 600)), max_seq_len=max_seq, block_size=bs,
-                num_blocks=n_req * ((max_seq + bs - 1) // bs) + int(rng.integers(0, 4)), weight_seed=1000 + seed,
-                weight_gain=0.0, shared=bool(rng.integers(0, 2)))
-    # (the fixtures' conditioning: 0.35 at dim 96, 0.30 at dim 288; wider models with such weights saturate the softmax
-    #  and the logits' differences stop being rounding)
-    spec["weight_gain"] = float(min(0.35, 5.0 / np.sqrt(spec["dim"])))
-    gen = int(rng.integers(4, 14))
-    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=int(rng.integers(0, max_seq - gen - 2))).tolist()
-               for _ in range(n_req)]
-    join = [0] + [int(rng.integers(0, 5)) for _ in range(n_req - 1)]
-    chunk = int(rng.choice([1, 3, 7, 16, 200]))  # prompt tokens fed per step
-    what = f"seed {seed}: {spec} prompts {[len(q) for q in prompts]} join {join} chunk {chunk}"
-    V = spec["vocab_size"]
-    with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "m.bin")
-        write_checkpoint(path, spec)
-        # (the checker's model, like the reference's, takes every layer's blocks from one manager)
-        oracles = [ol.ORACLE.oracle_model_create(path.encode(), bs, spec["n_layers"] * ((max_seq + bs - 1) // bs + 1))
-                   for _ in range(n_req)]
-        assert all(oracles), what
-        o_pos = [0] * n_req
-        want = np.empty(V, np.float32)
-
-        def oracle_feed(r, tokens):  # returns the logits behind the last token
-            for i, t in enumerate(tokens):
-                last = i == len(tokens) - 1
-                rc = ol.ORACLE.oracle_model_forward(oracles[r], int(t), o_pos[r], want.ctypes.data_as(C.c_void_p) if last else None)
-                assert rc == 0, f"{what}: checker refused token {o_pos[r]} of request {r}"
-                o_pos[r] += 1
-            return want
-
-        try:
-            with nv.LlamaModel(path, bs, spec["num_blocks"], max_seqs=n_req) as m:
-                fed = [0] * n_req          # prompt tokens already given
-                out = [[] for _ in range(n_req)]
-                joined = [False] * n_req
-                for step in range(400):
-                    ids, chunks = [], []
-                    for r in range(n_req):
-                        if join[r] > step or len(out[r]) >= gen:
-                            continue
-                        if not joined[r]:
-                            m.add_request(10 + r)
-                            joined[r] = True
-                        if fed[r] < len(prompts[r]):
-                            piece = prompts[r][fed[r]:fed[r] + chunk]
-                            fed[r] += len(piece)
-                        else:
-                            piece = [out[r][-1]]
-                        ids.append(r), chunks.append(piece)
-                    if not ids:
-                        if all(len(o) >= gen for o in out):
-                            break
-                        continue
-                    nxt, logits = m.step_chunks([10 + r for r in ids], chunks, True)
-                    for row, (r, piece) in enumerate(zip(ids, chunks)):
-                        ref = oracle_feed(r, piece)
-                        got = logits[row]
-                        err = np.abs(got - ref)
-                        # (the fixtures' logits are O(5); these reach 50 at dim 768, so the bar gets a term in the row's scale)
-                        bar = 2e-3 + 1e-4 * np.abs(ref) + 1e-4 * float(np.abs(ref).max())
-                        assert np.isfinite(got).all() and (err <= bar).all(), \
-                            f"{what}: step {step} request {r} at {o_pos[r]} tokens: max err {err.max():.3e}, largest logit {np.abs(ref).max():.1f}"
-                        top = np.sort(ref)[-2:]
-                        if fed[r] >= len(prompts[r]):  # the token behind a finished prompt, or behind a decode token
-                            if top[1] - top[0] > 2 * float(bar.max()):
-                                assert int(nxt[row]) == int(np.argmax(ref)), f"{what}: step {step} request {r}: argmax"
-                            out[r].append(int(nxt[row]))
-                            if len(out[r]) >= gen:
-                                m.finish_request(10 + r)
-                assert all(len(o) >= gen for o in out), what
-                assert m.free_blocks == spec["num_blocks"], what
-        finally:
-            for o in oracles:
-                ol.ORACLE.oracle_model_destroy(o)
-
+from fuzz_cases import model_case, noalloc_case, projection_case  # noqa: E402
 
 SWEEPS = [
     ("model: random checkpoints, batches", model_case),
+    ("model group: members on one device", lambda seed: model_case(seed, True)),
     ("decode: the no-alloc entry point", noalloc_case),
     ("projections: every entry point", projection_case),
     ("decode: auto / single pass / split-K", ta.test_random_geometry_batches_against_checker),
@@ -229,8 +35,9 @@ SWEEPS = [
     ("decode: skewed long chunks", tm.test_skewed_chunks_on_random_long_batches),
     ("prefill: paged chunks", tp.test_random_geometry_prefill_against_checker),
 ]
+SWEEPS_ALL = SWEEPS
 SWEEPS = [sw for sw in SWEEPS if args.only in sw[0]]
-budget = args.minutes * 60 / len(SWEEPS)
+budget = args.minutes * 60 / max(1, len(SWEEPS))
 bad = 0
 for name, fn in SWEEPS:
     t0, seed, fails, notes = time.perf_counter(), args.first, [], {}
@@ -250,4 +57,5 @@ for name, fn in SWEEPS:
     print(f"{name:40s} seeds {args.first}..{seed - 1} ({seed - args.first} cases, {time.perf_counter() - t0:.0f} s): "
           f"{len(fails)} failed {fails if fails else ''}{' ' + str(notes) if notes else ''}", flush=True)
     bad += len(fails)
-sys.exit(1 if bad else 0)
+if __name__ == "__main__":
+    sys.exit(1 if bad else 0)
