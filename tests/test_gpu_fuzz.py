@@ -29,3 +29,11 @@ def test_random_checkpoints_through_the_device_model(seed):
 @pytest.mark.parametrize("seed", range(5000, 5040))
 def test_random_checkpoints_through_a_group_of_models_on_one_device(seed):
     model_case(seed, group=True)
+
+
+@pytest.mark.parametrize("seed", range(100, 124))
+def test_random_checkpoints_with_fewer_blocks_than_the_requests_need(seed):
+    """A step that cannot get its blocks fails as a whole (model.hpp:190-207 throws "Out of memory: no free blocks"), no
+    request advances, no K/V row changes; the longest request is finished, the step repeated, and the others' logits still
+    match the checker to the end."""
+    model_case(seed, scarce=True)

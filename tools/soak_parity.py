@@ -28,6 +28,7 @@ from fuzz_cases import model_case, noalloc_case, projection_case  # noqa: E402
 SWEEPS = [
     ("model: random checkpoints, batches", model_case),
     ("model group: members on one device", lambda seed: model_case(seed, True)),
+    ("model: fewer blocks than needed", lambda seed: model_case(seed, False, True)),
     ("decode: the no-alloc entry point", noalloc_case),
     ("projections: every entry point", projection_case),
     ("decode: auto / single pass / split-K", ta.test_random_geometry_batches_against_checker),
