@@ -164,6 +164,11 @@ def model_case(seed, group=False, scarce=False):
             members = int(rng.integers(2, 4))
             with (nv.LlamaModelGroup(path, [0] * members, bs, spec["num_blocks"], max_seqs_per_member=n_req) if group
                   else nv.LlamaModel(path, bs, spec["num_blocks"], max_seqs=n_req)) as m:
+                graphs, linked = bool(rng.integers(0, 4)), bool(rng.integers(0, 3) == 0)
+                m.use_graphs(graphs)  # (on by default)
+                if not group:
+                    m.use_linked_norms(linked)  # (off by default: a few ulp from the separate norm kernels)
+                what += f" graphs {graphs} linked norms {linked and not group}"
                 fed = [0] * n_req          # prompt tokens already given
                 out = [[] for _ in range(n_req)]
                 joined = [False] * n_req
