@@ -101,7 +101,7 @@ def noalloc_case(seed):
         assert np.isfinite(b).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: bits differ"
 
 
-def model_case(seed, group=False, scarce=False):
+def model_case(seed, group=False, scarce=False, big=False):
     """(group: the same through nvk_model_group_* -- two or three models on device 0 standing in for as many GPUs, each
     request placed on one of them at admission.)
     A random llama2.c checkpoint (head geometry, layers, widths, vocabulary, block size, shared or own classifier)
@@ -118,16 +118,17 @@ def model_case(seed, group=False, scarce=False):
 
     rng = np.random.default_rng(seed)
     while True:
-        hd = int(rng.choice([4, 8, 16, 20, 32, 48, 64, 128]))
+        hd = int(rng.choice([64, 128]) if big else rng.choice([4, 8, 16, 20, 32, 48, 64, 128]))
         KV = int(rng.choice([1, 2, 3, 4, 6, 8]))
         H = KV * int(rng.choice([1, 2, 3, 4, 8]))
-        if H * hd <= 768:
+        if (H * hd in (1024, 2048, 4096)) if big else (H * hd <= 768):
             break
     bs = int(rng.choice([4, 8, 16, 32]))
-    n_req = int(rng.integers(1, 7))
-    max_seq = int(rng.integers(48, 129))
-    spec = dict(dim=H * hd, hidden_dim=4 * int(rng.integers(8, 300)), n_layers=int(rng.integers(1, 5)), n_heads=H,
-                n_kv_heads=KV, vocab_size=int(rng.integers(40, 600)), max_seq_len=max_seq, block_size=bs,
+    n_req = int(rng.choice([1, 2, 3, 8, 16, 17, 24, 33, 40]) if big else rng.integers(1, 7))
+    max_seq = int(rng.integers(24, 40) if big else rng.integers(48, 129))
+    spec = dict(dim=H * hd, hidden_dim=int(rng.choice([2816, 5632, 11008])) if big else 4 * int(rng.integers(8, 300)),
+                n_layers=int(rng.integers(1, 3) if big else rng.integers(1, 5)), n_heads=H,
+                n_kv_heads=KV, vocab_size=int(rng.choice([8000, 32000]) if big else rng.integers(40, 600)), max_seq_len=max_seq, block_size=bs,
                 num_blocks=n_req * ((max_seq + bs - 1) // bs) + int(rng.integers(0, 4)), weight_seed=1000 + seed,
                 weight_gain=0.0, shared=bool(rng.integers(0, 2)))
     # (the fixtures' conditioning: 0.35 at dim 96, 0.30 at dim 288; wider models with such weights saturate the softmax
@@ -135,8 +136,8 @@ def model_case(seed, group=False, scarce=False):
     spec["weight_gain"] = float(min(0.35, 5.0 / np.sqrt(spec["dim"])))
     if scarce:
         spec["num_blocks"] = max(2, int(spec["num_blocks"] * rng.uniform(0.25, 0.8)))
-    gen = int(rng.integers(4, 14))
-    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=int(rng.integers(0, max_seq - gen - 2))).tolist()
+    gen = int(rng.integers(2, 5) if big else rng.integers(4, 14))
+    prompts = [[1] + rng.integers(3, spec["vocab_size"], size=int(rng.integers(0, 8 if big else max_seq - gen - 2))).tolist()
                for _ in range(n_req)]
     join = [0] + [int(rng.integers(0, 5)) for _ in range(n_req - 1)]
     chunk = int(rng.choice([1, 3, 7, 16, 200]))  # prompt tokens fed per step
@@ -150,9 +151,8 @@ def model_case(seed, group=False, scarce=False):
                    for _ in range(n_req)]
         assert all(oracles), what
         o_pos = [0] * n_req
-        want = np.empty(V, np.float32)
-
         def oracle_feed(r, tokens):  # returns the logits behind the last token
+            want = np.empty(V, np.float32)
             for i, t in enumerate(tokens):
                 last = i == len(tokens) - 1
                 rc = ol.ORACLE.oracle_model_forward(oracles[r], int(t), o_pos[r], want.ctypes.data_as(C.c_void_p) if last else None)
@@ -200,10 +200,14 @@ def model_case(seed, group=False, scarce=False):
                         out[victim] = [0] * gen  # (counts as done)
                         dropped += 1
                         continue
+                    if big:  # the checker's forward passes of this step, a request to a thread (ctypes drops the GIL)
+                        from concurrent.futures import ThreadPoolExecutor
+                        with ThreadPoolExecutor(16) as ex:
+                            refs = list(ex.map(lambda a: oracle_feed(*a).copy(), zip(ids, chunks)))
                     for row, (r, piece) in enumerate(zip(ids, chunks)):
                         if fed[r] < len(prompts[r]):
                             fed[r] += len(piece)
-                        ref = oracle_feed(r, piece)
+                        ref = refs[row] if big else oracle_feed(r, piece)
                         got = logits[row]
                         err = np.abs(got - ref)
                         # (the fixtures' logits are O(5); these reach 50 at dim 768, so the bar gets a term in the row's scale)

@@ -29,6 +29,7 @@ SWEEPS = [
     ("model: random checkpoints, batches", model_case),
     ("model group: members on one device", lambda seed: model_case(seed, True)),
     ("model: fewer blocks than needed", lambda seed: model_case(seed, False, True)),
+    ("model: real widths", lambda seed: model_case(seed, big=True)),
     ("decode: the no-alloc entry point", noalloc_case),
     ("projections: every entry point", projection_case),
     ("decode: auto / single pass / split-K", ta.test_random_geometry_batches_against_checker),
