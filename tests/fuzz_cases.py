@@ -65,6 +65,46 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def prefill_long_case(seed):
+    """Paged chunked prefill deep into long prompts: 1-3 sequences, chunks of up to 400 queries behind up to 4000 cached
+    tokens (split keys, tile skipping under the causal line, ragged last tiles), every form, against the checker (query b
+    is the decode attention over start + b + 1 tokens; the checker's rows spread over host threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle_lib as ol
+    from nano_vllm_amd import workloads as wl
+
+    rng = np.random.default_rng(seed)
+    KV = int(rng.choice([1, 2, 4, 8]))
+    H = KV * int(rng.choice([1, 2, 4, 8]))
+    hd = int(rng.choice([48, 64, 128]))
+    bs = int(rng.choice([8, 16, 32]))
+    n = int(rng.integers(1, 4))
+    starts = rng.integers(0, int(rng.choice([300, 1500, 4000])), size=n).astype(np.int32)
+    lens = rng.integers(1, int(rng.choice([40, 150, 400])), size=n).astype(np.int32)
+    g = wl.Geometry(H, KV, hd, bs)
+    work = wl.fragmented_workload(f"plong{seed}", starts + lens, g, slack=0.2, perm_seed=seed)
+    k_host, v_host, tabs, _ = wl.host_blocks_for(work, list(range(n)))
+    total = int(lens.sum())
+    q = (rng.random((total, H, hd), dtype=np.float32) - np.float32(0.5)) * np.float32(rng.choice([1, 2, 4]))
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(int)
+    pieces = [(s, a, min(a + 32, int(offs[s + 1]))) for s in range(n) for a in range(int(offs[s]), int(offs[s + 1]), 32)]
+
+    def rows(piece):
+        s, a, b = piece
+        return ol.oracle_paged_prefill(q[a:b], k_host, v_host, tabs[s], int(starts[s]) + a - int(offs[s]), bs, KV)
+
+    with ThreadPoolExecutor(16) as ex:
+        want = np.concatenate(list(ex.map(rows, pieces)))
+    what = f"seed {seed}: H{H} KV{KV} hd{hd} bs{bs} starts {starts.tolist()} lens {lens.tolist()}"
+    with nv.PagedKVPool(1, work.num_blocks, bs, KV, hd) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for flags in (nv.PREFILL_ROWWISE, nv.PREFILL_TILED, nv.PREFILL_AUTO):
+            got = nv.prefill(pool, 0, q, work.block_tables, starts, lens, flags)
+            err = np.abs(got - want)
+            assert np.isfinite(got).all() and (err <= 1e-4 + 1e-5 * np.abs(want)).all(), f"{what} flags={flags}: max err {err.max():.3e}"
+
+
 def noalloc_case(seed):
     """nvk_decode_device_noalloc (the entry point that allocates nothing) against nvk_decode_device, bit for bit, on a
     random geometry / batch / mode; sizes past its stated maximum must be refused with an error, nothing else."""

@@ -6,7 +6,7 @@ path (an allocation, a device-wide wait); that used to invalidate the recording 
 -- against the checker's LlamaModel::forward (include/core/model.hpp:150-247)."""
 import pytest
 
-from fuzz_cases import model_case, noalloc_case, projection_case
+from fuzz_cases import model_case, noalloc_case, prefill_long_case, projection_case
 
 pytestmark = pytest.mark.gpu
 
@@ -37,3 +37,8 @@ def test_random_checkpoints_with_fewer_blocks_than_the_requests_need(seed):
     request advances, no K/V row changes; the longest request is finished, the step repeated, and the others' logits still
     match the checker to the end."""
     model_case(seed, scarce=True)
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_prefill_deep_into_long_prompts(seed):
+    prefill_long_case(seed)
