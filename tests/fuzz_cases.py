@@ -65,6 +65,56 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def decode_large_case(seed):
+    """Decode at the sizes the launch shapes were tuned on: the BASELINE geometries and their neighbours, 10-600
+    sequences, contexts to 20 000 tokens (ragged, some empty, some uniform), fragmented tables; every mode and modifier
+    (plan kernel with thousands of items, plan-free and uniform launches with skewed chunks, in-kernel and separate merge,
+    the vector kernel where the MFMA one would run, free-running waves, whole-row pairs) against the checker."""
+    import oracle_lib as ol
+    from nano_vllm_amd import workloads as wl
+
+    rng = np.random.default_rng(seed)
+    H, KV, hd = [(32, 8, 128), (32, 4, 128), (32, 4, 64), (64, 8, 128), (32, 32, 128), (16, 4, 128), (4, 1, 128), (8, 8, 64),
+                 (40, 8, 128), (6, 6, 48), (128, 8, 128), (16, 1, 128), (12, 2, 64), (32, 8, 64)][int(rng.integers(0, 14))]
+    bs = int(rng.choice([16, 16, 16, 8, 32]))
+    shape = int(rng.integers(0, 4))
+    if shape == 0:    # many short sequences (5a)
+        n, top = int(rng.integers(100, 600)), int(rng.choice([64, 256, 600]))
+    elif shape == 1:  # a batch of medium ones (configs 2, 3)
+        n, top = int(rng.integers(10, 130)), int(rng.choice([1024, 2048, 4096]))
+    elif shape == 2:  # few long ones (config 4)
+        n, top = int(rng.integers(1, 9)), int(rng.choice([8192, 20000]))
+    else:             # mixed
+        n, top = int(rng.integers(10, 200)), int(rng.choice([300, 3000]))
+    # (keep the checker's work bounded: ~ tokens x q-heads x head_dim)
+    while n * top * H * hd > 6e9 and n > 1:
+        n = max(1, n // 2)
+    uniform = rng.random() < 0.25
+    ctx = np.full(n, top, np.int32) if uniform else rng.integers(0, top + 1, size=n).astype(np.int32)
+    ctx[int(rng.integers(0, n))] = top
+    g = wl.Geometry(H, KV, hd, bs)
+    work = wl.fragmented_workload(f"large{seed}", ctx, g, slack=0.1, perm_seed=seed)
+    q = work.q() * np.float32(rng.choice([1, 3]))
+    k_host, v_host, tabs, c = wl.host_blocks_for(work, list(range(n)))
+    want = ol.oracle_decode_batch(q, k_host, v_host, tabs, c, bs, KV, n_threads=16)
+    chunk = int(rng.choice([128, 256, 512, 1024, 2048]))
+    modes = [(nv.AUTO, 0), (nv.SPLIT_K, chunk), (nv.SPLIT_K | nv.NO_PLAN, chunk), (nv.SPLIT_K | nv.MERGE_SEPARATE, chunk),
+             (nv.AUTO | nv.VECTOR_ONLY, 0), (nv.AUTO | nv.FREE_RUNNING, 0), (nv.AUTO | nv.NO_PAIRS, 0), (nv.SINGLE_PASS, 0)]
+    if uniform:
+        modes += [(nv.AUTO | nv.UNIFORM, 0), (nv.SPLIT_K | nv.UNIFORM, chunk)]
+    if KV == 8 and hd == 128:
+        modes.append((nv.AUTO | nv.ROW_PAIRS, 0))
+    what = f"seed {seed}: H{H} KV{KV} hd{hd} bs{bs}, {n} sequences to {top} tokens{' (uniform)' if uniform else ''}"
+    with nv.PagedKVPool(1, work.num_blocks, bs, KV, hd) as pool:
+        pool.fill_uniform(0, wl.SEED_K, wl.SEED_V)
+        for i in rng.permutation(len(modes))[:4]:
+            flags, ch = modes[int(i)]
+            got = nv.decode(pool, 0, q, work.block_tables, work.ctx_lens, flags, ch)
+            err = np.abs(got - want)
+            assert np.isfinite(got).all() and (err <= 1e-4 + 1e-5 * np.abs(want)).all(), \
+                f"{what} flags={flags:#x} chunk={ch}: max err {err.max():.3e} in row {np.unravel_index(err.argmax(), err.shape)}"
+
+
 def prefill_long_case(seed):
     """Paged chunked prefill deep into long prompts: 1-3 sequences, chunks of up to 400 queries behind up to 4000 cached
     tokens (split keys, tile skipping under the causal line, ragged last tiles), every form, against the checker (query b

@@ -6,7 +6,7 @@ path (an allocation, a device-wide wait); that used to invalidate the recording 
 -- against the checker's LlamaModel::forward (include/core/model.hpp:150-247)."""
 import pytest
 
-from fuzz_cases import model_case, noalloc_case, prefill_long_case, projection_case
+from fuzz_cases import decode_large_case, model_case, noalloc_case, prefill_long_case, projection_case
 
 pytestmark = pytest.mark.gpu
 
@@ -42,3 +42,8 @@ def test_random_checkpoints_with_fewer_blocks_than_the_requests_need(seed):
 @pytest.mark.parametrize("seed", range(100, 116))
 def test_prefill_deep_into_long_prompts(seed):
     prefill_long_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_decode_on_large_batches_with_every_modifier(seed):
+    decode_large_case(seed)

@@ -23,7 +23,7 @@ import test_gpu_attention as ta  # noqa: E402
 import test_gpu_fused_merge as tm  # noqa: E402
 import test_gpu_prefill as tp  # noqa: E402
 
-from fuzz_cases import model_case, noalloc_case, prefill_long_case, projection_case  # noqa: E402
+from fuzz_cases import decode_large_case, model_case, noalloc_case, prefill_long_case, projection_case  # noqa: E402
 
 SWEEPS = [
     ("model: random checkpoints, batches", model_case),
@@ -32,6 +32,7 @@ SWEEPS = [
     ("model: real widths", lambda seed: model_case(seed, big=True)),
     ("decode: the no-alloc entry point", noalloc_case),
     ("prefill: deep into long prompts", prefill_long_case),
+    ("decode: large batches, every modifier", decode_large_case),
     ("projections: every entry point", projection_case),
     ("decode: auto / single pass / split-K", ta.test_random_geometry_batches_against_checker),
     ("decode: in-kernel merge, plan-free", tm.test_in_kernel_merge_and_planless_decode_on_random_geometries),
