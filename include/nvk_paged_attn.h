@@ -117,7 +117,8 @@ int nvk_pool_geometry(const nvk_pool *pool, int *out6);
 /* device base addresses of one layer's K and V slabs (for callers that fill
  * the pool with their own kernels, e.g. a fused RoPE+append) */
 int nvk_pool_layer_ptrs(const nvk_pool *pool, int layer, void **k_dev, void **v_dev);
-/* the pool's own HIP stream (hipStream_t) */
+/* the pool's own HIP stream (hipStream_t; non-blocking).  It changes only when a model that owns the pool had a graph
+ * recording invalidated from outside the library and took a fresh one (Threads): ask again then. */
 int nvk_pool_stream(const nvk_pool *pool, void **stream);
 /* Counts the (re)allocations of the split-K workspace: launches recorded in a hipGraph hold its address. */
 long long nvk_pool_workspace_generation(const nvk_pool *pool);

@@ -200,6 +200,7 @@ int nvk_batch_create(nvk_pool *pool, nvk_block_manager *bm, int max_seqs, int ma
 
 int nvk_batch_destroy(nvk_batch *batch)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     release(batch);
     return NVK_OK;
 }
@@ -707,6 +708,7 @@ int nvk_batch_graph_signature(const nvk_batch *b, long long *out8)
 
 int nvk_batch_abort_step(nvk_batch *b)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!b)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_abort_step: null batch");
     // no request advances; blocks drawn for the step stay with their requests (the next step needs them anyway)
@@ -718,6 +720,7 @@ int nvk_batch_abort_step(nvk_batch *b)
 
 int nvk_batch_end_step(nvk_batch *b)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!b || !b->in_step)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_batch_end_step: no step in flight");
     for (size_t i = 0; i < b->step_ids.size(); i++)

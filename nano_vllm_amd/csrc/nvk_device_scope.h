@@ -4,15 +4,105 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 
 #include "nvk_internal.h"
 
 namespace nvk {
 
+// The recording gate.  A model records its decode step as a hipGraph (stream capture, nvk_model_step_chunks).  While a
+// stream of the process is capturing, ROCm 7.2 refuses work that other threads put on the null stream ("operation would
+// make the legacy stream depend on a capturing blocking stream" -- also for a non-blocking capturing stream, in
+// thread-local capture mode), refuses first-use work such as allocations, and any such call invalidates the recording and
+// leaves the recording stream unusable for good.  So the library keeps its own calls out of each other's way: every
+// entry point that touches the device holds the gate shared for its duration (the outermost one of a thread: entry
+// points call each other), a recording holds it alone, for the microseconds it takes.  Writers go first, so a recording
+// cannot starve behind threads that step back to back.  (What the APPLICATION does on other threads during a recording
+// is outside the library's reach: INTEGRATION.md.)
+class RecordGate
+{
+    std::mutex              m_;
+    std::condition_variable cv_;
+    int                     readers_ = 0, writers_waiting_ = 0;
+    bool                    writer_ = false;
+
+  public:
+    void lock_shared()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return !writer_ && writers_waiting_ == 0; });
+        ++readers_;
+    }
+    void unlock_shared()
+    {
+        std::lock_guard<std::mutex> l(m_);
+        if (--readers_ == 0)
+            cv_.notify_all();
+    }
+    void lock()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        ++writers_waiting_;
+        cv_.wait(l, [&] { return !writer_ && readers_ == 0; });
+        --writers_waiting_;
+        writer_ = true;
+    }
+    void unlock()
+    {
+        std::lock_guard<std::mutex> l(m_);
+        writer_ = false;
+        cv_.notify_all();
+    }
+};
+inline RecordGate &record_gate()
+{
+    static RecordGate gate;
+    return gate;
+}
+inline thread_local int g_gate_depth = 0; // entry points of this thread that are inside NVK_SCOPE
+
+// An entry point's shared hold of the gate (the outermost one of the thread takes it).
+struct GateHold
+{
+    GateHold()
+    {
+        if (g_gate_depth++ == 0)
+            record_gate().lock_shared();
+    }
+    ~GateHold()
+    {
+        if (--g_gate_depth == 0)
+            record_gate().unlock_shared();
+    }
+    GateHold(const GateHold &)            = delete;
+    GateHold &operator=(const GateHold &) = delete;
+};
+
+// Held by the thread that records: gives up the thread's shared hold, takes the gate alone, and puts things back.
+struct RecordAlone
+{
+    RecordAlone()
+    {
+        if (g_gate_depth > 0)
+            record_gate().unlock_shared();
+        record_gate().lock();
+    }
+    ~RecordAlone()
+    {
+        record_gate().unlock();
+        if (g_gate_depth > 0)
+            record_gate().lock_shared();
+    }
+    RecordAlone(const RecordAlone &)            = delete;
+    RecordAlone &operator=(const RecordAlone &) = delete;
+};
+
 // Makes `device` current and restores the caller's device after; when it already is current (the usual case: one
 // process per GPU) nothing is set or restored -- the entry points are called hundreds of times per model step.
 struct DeviceScope
 {
+    GateHold hold; // (first: taken before the device is touched, given back last)
     int  previous = -1;
     bool ok       = true;
     explicit DeviceScope(int device)

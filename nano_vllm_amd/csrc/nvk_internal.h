@@ -53,6 +53,12 @@ int  linked_gemv(const NormLink &link, bool glu, float *out_dev, const float *in
                 const float *w1_dev, int rows, int in_dim, int out_dim, int device, void *stream,
                 float *scratch_dev = nullptr); // glu with more than two rows: [rows, out_dim], contents unspecified after
 
+// After a graph recording on the pool's stream was invalidated from outside (another thread of the application put work
+// on the null stream or waited for the device meanwhile): ROCm 7.2 leaves such a stream in the state "invalidated" for
+// good -- every later call on it fails, ending the recording again is refused (tools/capture_recovery_probe.hip).  This
+// waits for the device, gives the pool a fresh stream and destroys the old one.  NVK_OK also when the stream is fine.
+int pool_renew_stream_if_stuck(nvk_pool *pool);
+
 constexpr int kFusedRowsMax = 16; // the GEMV (1-2 rows) and the 16-row MFMA kernel carry the fused epilogues
 int pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const int *block_tables_dev, int max_blocks,
                             const int *positions_dev, RopeAppendTarget *out);

@@ -22,8 +22,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <shared_mutex>
 #include <vector>
 
 #include "nvk_device_scope.h"
@@ -360,6 +358,7 @@ int nvk_model_load(const char *checkpoint_path, int block_size, int num_blocks, 
 
 int nvk_model_destroy(nvk_model *model)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     release(model);
     return NVK_OK;
 }
@@ -396,6 +395,7 @@ int nvk_model_request_len(const nvk_model *m, int request_id)
 
 int nvk_model_use_linked_norms(nvk_model *m, int on)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!m)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_use_linked_norms: null model");
     m->use_linked = on != 0;
@@ -448,15 +448,6 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
     if (rows > 0x3fffffffLL)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_model_step_chunks: %lld rows in one step", rows);
     NVK_SCOPE(m->device);
-    // Several models may live on one device, each stepped by a thread of its own (nvk_model_group_* with a device named
-    // twice; two engines in one process).  While one of them RECORDS its step (stream capture, below), no other may be
-    // inside a step on that device: a first-use path there -- an allocation, a fill on the null stream, a device-wide
-    // wait -- invalidates the recording even in thread-local capture mode, and the runtime then leaves the recording
-    // stream unusable (every later call on it: "operation failed due to a previous error during capture").  Steps hold
-    // the device's gate shared; a recording holds it alone, for the microseconds it takes.
-    static std::shared_mutex            record_gate[64];
-    std::shared_mutex                  &gate_mutex = record_gate[m->device & 63];
-    std::shared_lock<std::shared_mutex> gate(gate_mutex);
     int         rc = reserve_rows(m, (int)rows);
     if (rc != NVK_OK)
         return rc;
@@ -609,8 +600,8 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
                 // record the body (nothing runs while capturing); any refusal -- a first-use allocation inside an entry
                 // point, say -- ends the capture and this step runs directly
                 hipGraph_t graph = nullptr;
-                gate.unlock();
-                std::unique_lock<std::shared_mutex> alone(gate_mutex); // (see the gate above)
+                // (nobody else of the library on the device meanwhile: nvk_device_scope.h, the recording gate)
+                nvk::RecordAlone alone;
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                     const int  rb = enqueue_body();
                     hipError_t ec = hipStreamEndCapture(st, &graph);
@@ -629,12 +620,19 @@ int nvk_model_step_chunks(nvk_model *m, const int *request_ids, const int *chunk
                         (void)hipGetLastError(); // clear the sticky capture error
                         if (++m->graph_failures >= 4)
                             m->use_graphs = false;
+                        // a recording invalidated from outside the library leaves the stream unusable: take a fresh one
+                        if (nvk::pool_renew_stream_if_stuck(m->pool) == NVK_OK) {
+                            void *fresh = nullptr;
+                            if (nvk_pool_stream(m->pool, &fresh) == NVK_OK && fresh != (void *)st) {
+                                st = m->stream = (hipStream_t)fresh;
+                                if (std::getenv("NVK_GRAPH_DEBUG"))
+                                    std::fprintf(stderr, "nvk_model: the recording was invalidated from outside; new stream\n");
+                            }
+                        }
                     }
                     if (graph)
                         (void)hipGraphDestroy(graph);
                 }
-                alone.unlock();
-                gate.lock();
             }
             if (m->graph_exec) {
                 if (hipGraphLaunch(m->graph_exec, st) == hipSuccess)

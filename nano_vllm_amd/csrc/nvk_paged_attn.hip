@@ -1207,6 +1207,7 @@ int nvk_device_count(void)
 int nvk_pool_create(int n_layers, int num_blocks, int block_size, int n_kv_heads, int head_dim, int device,
                     nvk_pool **out_pool)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!out_pool)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_pool_create: out_pool is null");
     *out_pool = nullptr;
@@ -1320,6 +1321,7 @@ int nvk_pool_set_rope_theta(nvk_pool *pool, float rope_theta)
 
 int nvk_pool_destroy(nvk_pool *pool)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!pool)
         return NVK_OK;
     nvk::DeviceScope scope(pool->device);
@@ -1560,6 +1562,31 @@ int nvk_pool_rope_append_batch(nvk_pool *pool, int layer, int num_seqs, int n_he
 
 } // extern "C"
 
+int nvk::pool_renew_stream_if_stuck(nvk_pool *pool)
+{
+    if (!pool)
+        return nvk::fail(NVK_ERR_INVALID_ARG, "pool_renew_stream_if_stuck: null pool");
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(pool->stream, &status) == hipSuccess && status == hipStreamCaptureStatusNone)
+        return NVK_OK;
+    (void)hipGetLastError();
+    NVK_SCOPE(pool->device);
+    hipStream_t fresh = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    // (what was enqueued before the recording began has to be over before anything follows it on the new stream; the old
+    //  stream itself can no longer be waited for)
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(fresh);
+        return nvk::fail(NVK_ERR_HIP, "pool_renew_stream_if_stuck: hipDeviceSynchronize failed: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamDestroy(pool->stream);
+    (void)hipGetLastError();
+    pool->stream = fresh;
+    return NVK_OK;
+}
+
+
 int nvk::pool_rope_append_target(nvk_pool *pool, int layer, float rope_theta, const int *block_tables_dev, int max_blocks,
                                  const int *positions_dev, RopeAppendTarget *out)
 {
@@ -1717,6 +1744,7 @@ int nvk_plan_create(nvk_pool *pool, nvk_plan **out_plan)
 
 int nvk_plan_destroy(nvk_plan *plan)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!plan)
         return NVK_OK;
     nvk::DeviceScope scope(plan->pool->device);
@@ -2169,11 +2197,15 @@ int nvk_decode_bench_graph(nvk_pool *pool, int first_layer, int n_rotate, int nu
     HIP_TRY(hipStreamSynchronize(st));
     hipGraph_t     graph = nullptr;
     hipGraphExec_t exec  = nullptr;
-    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < layers_per_graph && rc == NVK_OK; i++)
-        rc = enqueue_planned(pool, first_layer + i % n_rotate, plan, q_dev, block_tables_dev, max_blocks, out_dev, st,
-                             nullptr, nullptr);
-    hipError_t e = hipStreamEndCapture(st, &graph);
+    hipError_t     e     = hipSuccess;
+    {
+        nvk::RecordAlone alone; // (nvk_device_scope.h: no other call of the library while a stream of the process records)
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < layers_per_graph && rc == NVK_OK; i++)
+            rc = enqueue_planned(pool, first_layer + i % n_rotate, plan, q_dev, block_tables_dev, max_blocks, out_dev, st,
+                                 nullptr, nullptr);
+        e = hipStreamEndCapture(st, &graph);
+    }
     if (rc != NVK_OK) {
         if (graph)
             (void)hipGraphDestroy(graph);

@@ -159,6 +159,7 @@ int nvk_shard_unique_id(void *id128)
 int nvk_shard_create(int rank, int world, const void *id128, int device, int n_heads, int n_kv_heads,
                      nvk_shard **out_shard)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!out_shard)
         return nvk::fail(NVK_ERR_INVALID_ARG, "nvk_shard_create: out_shard is null");
     *out_shard = nullptr;
@@ -207,6 +208,7 @@ int nvk_shard_create(int rank, int world, const void *id128, int device, int n_h
 
 int nvk_shard_destroy(nvk_shard *s)
 {
+    nvk::GateHold hold; // (nvk_device_scope.h: not while a stream of the process records a graph)
     if (!s)
         return NVK_OK;
     nvk::DeviceScope scope(s->device);

@@ -47,3 +47,32 @@ def test_prefill_deep_into_long_prompts(seed):
 @pytest.mark.parametrize("seed", range(100, 116))
 def test_decode_on_large_batches_with_every_modifier(seed):
     decode_large_case(seed)
+
+
+def test_a_recording_invalidated_by_the_application_costs_the_graph_not_the_model():
+    """Another thread of the application waits for the device (or uses the null stream) while a model records its decode
+    step: ROCm 7.2 invalidates the recording and leaves the recording stream unusable for good
+    (tools/capture_recovery_probe.hip).  The model then takes a fresh stream and runs the step directly; after four such
+    failures it stops recording.  Its logits stay the checker's throughout."""
+    import ctypes as C
+    import threading
+
+    import numpy as np
+    from hipmem import DeviceArray, _hip
+
+    stop = threading.Event()
+    scratch = DeviceArray(np.zeros(64, np.int32))
+    _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+
+    def hammer():
+        while not stop.is_set():
+            _hip.hipMemset(scratch.ptr, 0, 256)  # null stream: refused while a recording is in progress, and invalidates it
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    try:
+        for seed in range(300, 312):
+            model_case(seed)
+    finally:
+        stop.set()
+        t.join()
