@@ -377,8 +377,10 @@ int nvk_standard_attention(float *out, const float *q, const float *key_cache, c
  *    for the same slab, rows are only appended (include/core/model.hpp:190-207,211-217) and num_tokens
  *    grows by one (:397).  A device mirror per slab (keyed by the key_cache pointer) then keeps what it
  *    has, and only new rows cross PCIe: 2 rows per call instead of 2 * num_tokens.  A call that is not
- *    "the previous call on this slab plus one token" restages everything, so a new request needs no
- *    notice; rewriting rows in place between such calls is what the promise forbids.
+ *    "the previous call on this slab plus one token" -- the same blocks in the same order (at most one
+ *    more) and num_tokens one higher -- restages everything, so a new request needs no notice, also
+ *    when it takes blocks another has just freed; rewriting rows in place between such calls is what
+ *    the promise forbids.
  * Switching back to RESTAGE frees the mirrors.  nvk_host_cache_staged_bytes: K/V bytes the drop-in
  * entry points have copied host-to-device on this thread (reset != 0 clears the counter). */
 #define NVK_HOST_CACHE_RESTAGE 0

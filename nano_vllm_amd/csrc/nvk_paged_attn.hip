@@ -76,6 +76,9 @@
 #ifndef NVK_KV_PAIRS
 #define NVK_KV_PAIRS 1 // 1: rows of 64 / 192 B are streamed a pair of adjacent kv-heads per wave (whole lines)
 #endif
+#ifndef NVK_MIRROR_TABLE_CHECK
+#define NVK_MIRROR_TABLE_CHECK 1 // 0 (A/B): the append-only host mirror trusts its rows on "one token more" alone
+#endif
 #ifndef NVK_FUSE_MAX_CHUNKS
 #define NVK_FUSE_MAX_CHUNKS 16 // chunks per sequence up to which the split-K combine runs inside the decode kernel (the
                                // workgroup that completes a sequence merges it: one CU's worth of reading, fine for a
@@ -1058,6 +1061,11 @@ struct HostMirror
     // bytes there: then nothing staged is trusted (a cheap check, one row; it cannot prove the promise kept).
     std::vector<float> witness;
     size_t             witness_at = 0; // float offset into k_host
+    // the block table of the last call: "the previous call plus one token" means the SAME sequence -- the same blocks in
+    // the same order, at most one more.  (Several requests decoding in turn over one layer's slab, one of them new on
+    // blocks another has just freed and holding exactly one token more than the call before: without this its blocks'
+    // old rows would be trusted.)
+    std::vector<int> last_table;
 };
 
 // The calling thread's device-side state behind the host-slab forms of the drop-in entry points; released when
@@ -2507,7 +2515,10 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
         nvk_pool   *mp = m->pool;
         NVK_SCOPE(mp->device);
         // not "the previous call plus one token", or the slab no longer holds what was staged last: trust nothing staged
-        if (num_tokens != m->last_tokens + 1 || !witness_holds(*m))
+        const bool same_sequence = !NVK_MIRROR_TABLE_CHECK
+                                   || ((size_t)nblk >= m->last_table.size() && (size_t)nblk <= m->last_table.size() + 1
+                                       && std::equal(m->last_table.begin(), m->last_table.end(), block_table));
+        if (num_tokens != m->last_tokens + 1 || !same_sequence || !witness_holds(*m))
             std::fill(m->rows_staged.begin(), m->rows_staged.end(), 0);
         for (int i = 0; i < nblk; i++) {
             auto it = m->local_of.find(block_table[i]);
@@ -2515,6 +2526,7 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
                 if ((int)m->rows_staged.size() >= mp->num_blocks) { // more distinct blocks than the mirror holds
                     m->local_of.clear();
                     m->rows_staged.clear();
+                    m->last_table.clear();
                     m->last_tokens = -1;
                     return nvk_paged_attention(out, q, key_cache, value_cache, block_table, att_scores, num_tokens,
                                                block_size, head_dim, n_heads, n_kv_heads); // remapped from scratch
@@ -2538,6 +2550,7 @@ int nvk_paged_attention(float *out, const float *q, const float *key_cache, cons
             local[(size_t)i] = lb;
         }
         m->last_tokens = num_tokens;
+        m->last_table.assign(block_table, block_table + nblk);
         keep_witness(*m, (size_t)block_table[(num_tokens - 1) / block_size] * blk + (size_t)((num_tokens - 1) % block_size) * row,
                      row);
         return nvk_decode(mp, 0, 1, n_heads, q, local.data(), nblk, &num_tokens, out, NVK_DECODE_AUTO, 0);

@@ -65,6 +65,72 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def dropin_case(seed):
+    """An engine's calls to the drop-in entry point with HOST slabs (Attention::paged_attention's eleven arguments,
+    include/core/attention.hpp:82-92), under both staging policies: two layer slabs, several requests decoding in turn,
+    requests finishing and new ones taking their blocks (lowest id first, as the reference's BlockManager hands them out),
+    prompts written token by token or many rows at once before the first decode call -- half of the new requests arrive
+    holding exactly one token more than the call before, on blocks just freed.  Every call against the checker on the
+    slabs as they are at that moment."""
+    import oracle_lib as ol
+
+    rng = np.random.default_rng(seed)
+    KV = int(rng.choice([1, 2, 4]))
+    H = KV * int(rng.choice([1, 2, 4]))
+    hd = int(rng.choice([16, 64]))
+    bs = int(rng.choice([4, 8, 16]))
+    nb, L = int(rng.integers(6, 30)), 2
+    k = [np.zeros((nb, bs, KV, hd), np.float32) for _ in range(L)]
+    v = [np.zeros((nb, bs, KV, hd), np.float32) for _ in range(L)]
+    free, live, next_id, last_tokens = list(range(nb)), {}, 0, 0
+    append_only = bool(rng.integers(0, 3))
+    what = f"seed {seed}: H{H} KV{KV} hd{hd} bs{bs}, {nb} blocks, append-only mirror {append_only}"
+
+    def write_row(req, pos):
+        while pos // bs >= len(req["table"]):
+            req["table"].append(free.pop(0))
+        pb, off = req["table"][pos // bs], pos % bs
+        for l in range(L):
+            k[l][pb, off] = rng.standard_normal((KV, hd), dtype=np.float32)
+            v[l][pb, off] = rng.standard_normal((KV, hd), dtype=np.float32)
+
+    nv.set_host_cache_policy(append_only)
+    try:
+        for step in range(int(rng.integers(30, 120))):
+            r = rng.random()
+            if live and r < 0.08:  # a request finishes: its blocks go back, lowest id first out again
+                done = live.pop(list(live)[int(rng.integers(0, len(live)))])
+                free.extend(done["table"])
+                free.sort()
+            if (not live or r > 0.85) and len(free) >= 2 and len(live) < 4:  # a new one, its prompt written in one go
+                room = len(free) * bs - 1
+                prompt = last_tokens if (rng.random() < 0.5 and 0 < last_tokens <= room) else int(rng.integers(0, min(room, 3 * bs) + 1))
+                live[next_id] = {"table": [], "len": 0}
+                for pos in range(prompt):
+                    write_row(live[next_id], pos)
+                live[next_id]["len"] = prompt
+                next_id += 1
+            if not live:
+                continue
+            req = live[list(live)[int(rng.integers(0, len(live)))]]
+            if req["len"] // bs >= len(req["table"]) and not free:
+                continue  # (no block for its next token)
+            write_row(req, req["len"])
+            req["len"] += 1
+            table = np.array(req["table"], np.int32)
+            for l in range(L):
+                q = rng.standard_normal((H, hd), dtype=np.float32)
+                out = np.full(H * hd, np.nan, np.float32)
+                nv.paged_attention(out, q, k[l], v[l], table, None, req["len"], bs, hd, H, KV)
+                want = ol.oracle_paged_attention(q, k[l], v[l], table, req["len"], bs, hd, H, KV).reshape(-1)
+                err = np.abs(out - want)
+                assert np.isfinite(out).all() and (err <= 1e-4 + 1e-5 * np.abs(want)).all(), \
+                    f"{what}: step {step} layer {l}, {req['len']} tokens over blocks {req['table']}: max err {err.max():.3e}"
+            last_tokens = req["len"]
+    finally:
+        nv.set_host_cache_policy(False)
+
+
 def decode_large_case(seed):
     """Decode at the sizes the launch shapes were tuned on: the BASELINE geometries and their neighbours, 10-600
     sequences, contexts to 20 000 tokens (ragged, some empty, some uniform), fragmented tables; every mode and modifier

@@ -6,7 +6,7 @@ path (an allocation, a device-wide wait); that used to invalidate the recording 
 -- against the checker's LlamaModel::forward (include/core/model.hpp:150-247)."""
 import pytest
 
-from fuzz_cases import decode_large_case, model_case, noalloc_case, prefill_long_case, projection_case
+from fuzz_cases import decode_large_case, dropin_case, model_case, noalloc_case, prefill_long_case, projection_case
 
 pytestmark = pytest.mark.gpu
 
@@ -76,3 +76,11 @@ def test_a_recording_invalidated_by_the_application_costs_the_graph_not_the_mode
     finally:
         stop.set()
         t.join()
+
+
+@pytest.mark.parametrize("seed", range(100, 160))
+def test_drop_in_entry_point_over_host_slabs_as_an_engine_calls_it(seed):
+    """Both staging policies.  The sweep found the append-only mirror trusting its rows on "one token more than the call
+    before" alone: a new request on just-freed blocks holding exactly that many tokens read the old request's rows
+    (seeds 101, 116, 133 ... of this range failed with errors of order 1).  The promise now also means the same blocks."""
+    dropin_case(seed)
