@@ -131,6 +131,48 @@ def dropin_case(seed):
         nv.set_host_cache_policy(False)
 
 
+def dropin_contiguous_case(seed):
+    """The same for the contiguous-cache twin (Attention::standard_attention, attention.hpp:16-76; one sequence per
+    slab, as LlamaModel::attention calls it, model.hpp:419-430): tokens appended one by one, now and then a new sequence
+    from row 0 -- its prompt written in one go, half of the time exactly as long as the last call's context -- under both
+    staging policies, two layer slabs, every call against the checker."""
+    import oracle_lib as ol
+
+    rng = np.random.default_rng(seed)
+    KV = int(rng.choice([1, 2, 4]))
+    H = KV * int(rng.choice([1, 2, 4]))
+    hd = int(rng.choice([16, 48, 64]))
+    S, L = int(rng.integers(8, 120)), 2
+    k = [np.zeros((S, KV, hd), np.float32) for _ in range(L)]
+    v = [np.zeros((S, KV, hd), np.float32) for _ in range(L)]
+    append_only = bool(rng.integers(0, 3))
+    what = f"seed {seed}: H{H} KV{KV} hd{hd}, max_seq_len {S}, append-only mirror {append_only}"
+    n = 0  # rows of the current sequence
+    nv.set_host_cache_policy(append_only)
+    try:
+        for step in range(int(rng.integers(20, 100))):
+            if n >= S or rng.random() < 0.07:  # a new sequence over the same slabs
+                last = n
+                n = last if (rng.random() < 0.5 and 1 <= last < S) else int(rng.integers(0, max(1, S // 2)))
+                for l in range(L):
+                    k[l][:n] = rng.standard_normal((n, KV, hd), dtype=np.float32)
+                    v[l][:n] = rng.standard_normal((n, KV, hd), dtype=np.float32)
+            for l in range(L):
+                k[l][n] = rng.standard_normal((KV, hd), dtype=np.float32)
+                v[l][n] = rng.standard_normal((KV, hd), dtype=np.float32)
+            n += 1
+            for l in range(L):
+                q = rng.standard_normal((H, hd), dtype=np.float32)
+                out = np.full(H * hd, np.nan, np.float32)
+                nv.standard_attention(out, q, k[l], v[l], None, n - 1, hd, H, KV, S)
+                want = ol.standard_attention(ol.ORACLE.oracle_standard_attention, q, k[l], v[l], n - 1, hd, H, KV, S).reshape(-1)
+                err = np.abs(out - want)
+                assert np.isfinite(out).all() and (err <= 1e-4 + 1e-5 * np.abs(want)).all(), \
+                    f"{what}: step {step} layer {l}, pos {n - 1}: max err {err.max():.3e}"
+    finally:
+        nv.set_host_cache_policy(False)
+
+
 def decode_large_case(seed):
     """Decode at the sizes the launch shapes were tuned on: the BASELINE geometries and their neighbours, 10-600
     sequences, contexts to 20 000 tokens (ragged, some empty, some uniform), fragmented tables; every mode and modifier
