@@ -65,6 +65,82 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def pool_ops_case(seed):
+    """The pool's filling and reading entry points in random order on a random geometry (odd head widths included): rows
+    appended one by one and in batches, RoPE + append (Ops::apply_rope, positional.hpp:13-39, then model.hpp:190-207),
+    whole blocks uploaded; against a host copy of the pool -- every block downloaded bit for bit (rotated K rows within
+    4e-7 of the checker's rotation), every kv-head gathered through a shuffled table, and one decode over it all."""
+    import oracle_lib as ol
+
+    rng = np.random.default_rng(seed)
+    KV = int(rng.choice([1, 2, 3, 4, 6, 8]))
+    H = KV * int(rng.choice([1, 2, 3, 4, 8]))
+    hd = int(rng.choice([4, 16, 20, 48, 64, 80, 128, 132, 256]))
+    bs = int(rng.choice([1, 4, 8, 16, 32]))
+    L, nb = int(rng.integers(1, 4)), int(rng.integers(3, 40))
+    theta = float(rng.choice([10000.0, 500000.0]))
+    hk = np.zeros((L, nb, bs, KV, hd), np.float32)
+    hv = np.zeros_like(hk)
+    loose = np.zeros((L, nb, bs), bool)  # slots holding a rotated K row (compared within the rotation's bar)
+    what = f"seed {seed}: {L} layers x {nb} blocks of {bs}, KV{KV} H{H} hd{hd}"
+    with nv.PagedKVPool(L, nb, bs, KV, hd) as pool:
+        for op in range(int(rng.integers(5, 40))):
+            l, kind = int(rng.integers(0, L)), int(rng.integers(0, 4))
+            if kind == 0:
+                pb, off = int(rng.integers(0, nb)), int(rng.integers(0, bs))
+                kr, vr = rng.standard_normal((KV, hd), dtype=np.float32), rng.standard_normal((KV, hd), dtype=np.float32)
+                pool.append(l, pb, off, kr, vr)
+                hk[l, pb, off], hv[l, pb, off], loose[l, pb, off] = kr, vr, False
+            elif kind == 3:
+                pb = int(rng.integers(0, nb))
+                kb, vb = rng.standard_normal((bs, KV, hd), dtype=np.float32), rng.standard_normal((bs, KV, hd), dtype=np.float32)
+                pool.upload_block(l, pb, kb, vb)
+                hk[l, pb], hv[l, pb], loose[l, pb] = kb, vb, False
+            else:  # a batch: n sequences over disjoint blocks, one new row each
+                n = int(rng.integers(1, min(nb, 9) + 1))
+                max_blocks = max(1, nb // n)
+                tabs = rng.permutation(nb)[: n * max_blocks].reshape(n, max_blocks).astype(np.int32)
+                pos = rng.integers(0, max_blocks * bs, size=n).astype(np.int32)
+                kr, vr = rng.standard_normal((n, KV, hd), dtype=np.float32), rng.standard_normal((n, KV, hd), dtype=np.float32)
+                if kind == 1:
+                    pool.append_batch(l, kr, vr, tabs, pos)
+                    want_k = kr
+                else:
+                    q = rng.standard_normal((n, H, hd), dtype=np.float32)
+                    q_rot = pool.rope_append_batch(l, q, kr, vr, tabs, pos, theta)
+                    want_k = np.empty_like(kr)
+                    for s_ in range(n):
+                        wq, want_k[s_] = ol.apply_rope(ol.ORACLE.oracle_apply_rope, q[s_], kr[s_], int(pos[s_]), hd, H, KV, theta)
+                        assert np.abs(q_rot[s_] - wq).max() <= 4e-7 * max(1.0, float(np.abs(wq).max())), f"{what}: op {op}: rotated q"
+                for s_ in range(n):
+                    pb, off = int(tabs[s_, pos[s_] // bs]), int(pos[s_] % bs)
+                    hk[l, pb, off], hv[l, pb, off], loose[l, pb, off] = want_k[s_], vr[s_], kind == 2
+        for l in range(L):
+            for pb in range(nb):
+                kb, vb = pool.download_block(l, pb)
+                assert np.array_equal(vb.view(np.uint32), hv[l, pb].view(np.uint32)), f"{what}: V of layer {l} block {pb}"
+                exact = ~loose[l, pb]
+                assert np.array_equal(kb[exact].view(np.uint32), hk[l, pb][exact].view(np.uint32)), f"{what}: K of layer {l} block {pb}"
+                if loose[l, pb].any():
+                    d = np.abs(kb[loose[l, pb]] - hk[l, pb][loose[l, pb]])
+                    assert d.max() <= 4e-7 * max(1.0, float(np.abs(hk[l, pb]).max())), f"{what}: rotated K of layer {l} block {pb}"
+                    hk[l, pb][loose[l, pb]] = kb[loose[l, pb]]  # (what the pool holds is what the reads below see)
+        l = int(rng.integers(0, L))
+        table = rng.permutation(nb).astype(np.int32)
+        T = int(rng.integers(1, nb * bs + 1))
+        for h in range(KV):
+            gk, gv = pool.gather(l, table, T, h)
+            lin_k = hk[l][table].reshape(nb * bs, KV, hd)[:T, h]
+            lin_v = hv[l][table].reshape(nb * bs, KV, hd)[:T, h]
+            assert np.array_equal(gk.view(np.uint32), lin_k.view(np.uint32)) and np.array_equal(gv.view(np.uint32), lin_v.view(np.uint32)), \
+                f"{what}: gather of kv-head {h}, {T} tokens"
+        q = rng.standard_normal((1, H, hd), dtype=np.float32)
+        got = nv.decode(pool, l, q, table[None, :], np.array([T], np.int32))
+        want = ol.oracle_paged_attention(q[0], hk[l], hv[l], table, T, bs, hd, H, KV)
+        err = np.abs(got[0] - want)
+        assert np.isfinite(got).all() and (err <= 1e-4 + 1e-5 * np.abs(want)).all(), f"{what}: decode over {T} tokens: max err {err.max():.3e}"
+
+
 def dropin_case(seed):
     """An engine's calls to the drop-in entry point with HOST slabs (Attention::paged_attention's eleven arguments,
     include/core/attention.hpp:82-92), under both staging policies: two layer slabs, several requests decoding in turn,
