@@ -65,6 +65,67 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def plan_case(seed):
+    """A model step's use of decode plans (nvk_plan_build once per step, nvk_decode_planned per layer), over several
+    steps of a batch whose sequences grow by a token, finish and join: each step the plan is rebuilt -- or, when the
+    lengths did not change, reused --, run on every layer of a pool whose layers hold different rows, and compared bit
+    for bit with nvk_decode_device of the same mode and, on one layer, with the checker.  Plans of different sizes follow
+    each other in one object (its work list and counters grow and are reused)."""
+    import oracle_lib as ol
+    from nano_vllm_amd import workloads as wl
+
+    rng = np.random.default_rng(seed)
+    KV = int(rng.choice([1, 2, 4, 8]))
+    H = KV * int(rng.choice([1, 2, 4, 8, 16]))
+    hd = int(rng.choice([16, 48, 64, 128]))
+    bs = int(rng.choice([8, 16, 32]))
+    L = int(rng.integers(1, 4))
+    n0 = int(rng.integers(1, 12))
+    top = int(rng.choice([60, 400, 2500]))
+    g = wl.Geometry(H, KV, hd, bs)
+    room = int(rng.integers(3, 12))  # tokens a sequence may grow by
+    ctx = rng.integers(0, top + 1, size=n0).astype(np.int32)
+    ctx[int(rng.integers(0, n0))] = top
+    work = wl.fragmented_workload(f"plan{seed}", ctx + room, g, slack=0.2, perm_seed=seed)
+    k_host, v_host, tabs, _ = wl.host_blocks_for(work, list(range(n0)))
+    flags, chunk = [(nv.AUTO, 0), (nv.SPLIT_K, int(rng.choice([16, 64, 256]))), (nv.SPLIT_K | nv.MERGE_SEPARATE, int(rng.choice([32, 128]))),
+                    (nv.SINGLE_PASS, 0)][int(rng.integers(0, 4))]
+    what = f"seed {seed}: H{H} KV{KV} hd{hd} bs{bs} L{L} flags={flags:#x} chunk={chunk}"
+    with nv.PagedKVPool(L, work.num_blocks, bs, KV, hd) as pool:
+        for l in range(L):
+            pool.fill_uniform(l, wl.SEED_K + l, wl.SEED_V + l)
+        plan = nv.DecodePlan(pool)
+        try:
+            alive = list(range(n0))
+            lens = ctx.copy()
+            for step in range(int(rng.integers(2, 7))):
+                if step and rng.random() < 0.7:
+                    lens[alive] = np.minimum(lens[alive] + 1, ctx[alive] + room)  # (a token each; otherwise the last plan still fits)
+                if len(alive) > 1 and rng.random() < 0.3:
+                    alive.pop(int(rng.integers(0, len(alive))))
+                n = len(alive)
+                q = rng.standard_normal((n, H, hd), dtype=np.float32)
+                qd, td = DeviceArray(q), DeviceArray(np.ascontiguousarray(work.block_tables[alive]))
+                cd = DeviceArray(np.ascontiguousarray(lens[alive]))
+                max_ctx = int(lens[alive].max()) if n else 0
+                plan.build(n, H, cd, max_ctx, flags, chunk)
+                for l in range(L):
+                    o1, o2 = DeviceArray(np.full_like(q, np.nan)), DeviceArray(np.full_like(q, np.nan))
+                    plan.run(l, qd, td, work.max_blocks, o1)
+                    nv.decode_device(pool, l, n, H, qd, td, work.max_blocks, cd, max_ctx, o2, flags, chunk)
+                    pool.synchronize()
+                    a, b = o1.numpy(), o2.numpy()
+                    assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+                        f"{what}: step {step} layer {l}: planned and direct launches differ"
+                    if l == 0:
+                        kh = wl.host_blocks_for(work, alive)  # (layer 0's fill is the workload's own)
+                        want = ol.oracle_decode_batch(q, kh[0], kh[1], kh[2], lens[alive], bs, KV, n_threads=8)
+                        err = np.abs(a - want)
+                        assert (err <= 1e-4 + 1e-5 * np.abs(want)).all(), f"{what}: step {step}: max err {err.max():.3e}"
+        finally:
+            plan.close()
+
+
 def pool_ops_case(seed):
     """The pool's filling and reading entry points in random order on a random geometry (odd head widths included): rows
     appended one by one and in batches, RoPE + append (Ops::apply_rope, positional.hpp:13-39, then model.hpp:190-207),

@@ -6,7 +6,7 @@ path (an allocation, a device-wide wait); that used to invalidate the recording 
 -- against the checker's LlamaModel::forward (include/core/model.hpp:150-247)."""
 import pytest
 
-from fuzz_cases import decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, pool_ops_case, prefill_long_case, projection_case
+from fuzz_cases import decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, plan_case, pool_ops_case, prefill_long_case, projection_case
 
 pytestmark = pytest.mark.gpu
 
@@ -94,3 +94,8 @@ def test_drop_in_contiguous_cache_entry_point_as_an_engine_calls_it(seed):
 @pytest.mark.parametrize("seed", range(100, 140))
 def test_pool_fill_and_read_entry_points_in_random_order(seed):
     pool_ops_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(100, 130))
+def test_decode_plans_over_the_steps_of_a_batch(seed):
+    plan_case(seed)
