@@ -65,6 +65,60 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+def shard_one_rank_case(seed):
+    """nvk_shard_* on a communicator of one rank (all a one-GPU box can form; the head slicing at world 2 and 4 is covered
+    on CPU over gloo): random geometry, batch and mode, both places the collective can run, the two-buffer protocol over
+    2-5 layer-calls -- gathered[0] must be what nvk_decode writes, bit for bit."""
+    from hipmem import Stream
+    from nano_vllm_amd import sharding as sh
+    from nano_vllm_amd import workloads as wl
+
+    rng = np.random.default_rng(seed)
+    KV = int(rng.choice([1, 2, 4, 8]))
+    H = KV * int(rng.choice([1, 2, 4, 8]))
+    hd = int(rng.choice([16, 48, 64, 128]))
+    bs = int(rng.choice([8, 16, 32]))
+    n = int(rng.integers(1, 10))
+    top = int(rng.choice([50, 600, 3000]))
+    ctx = rng.integers(0, top + 1, size=n).astype(np.int32)
+    ctx[int(rng.integers(0, n))] = top
+    g = wl.Geometry(H, KV, hd, bs)
+    work = wl.fragmented_workload(f"shard{seed}", ctx, g, slack=0.2, perm_seed=seed)
+    L = int(rng.integers(2, 6))
+    flags, chunk = [(nv.AUTO, 0), (nv.SPLIT_K, int(rng.choice([32, 128, 512]))), (nv.SINGLE_PASS, 0)][int(rng.integers(0, 3))]
+    what = f"seed {seed}: H{H} KV{KV} hd{hd} bs{bs} ctx{ctx.tolist()} L{L} flags={flags:#x} chunk={chunk}"
+    with nv.PagedKVPool(L, work.num_blocks, bs, KV, hd) as pool:
+        for layer in range(L):
+            pool.fill_uniform(layer, 10 + layer, 20 + layer)
+        shard = sh.NvkShard(0, 1, sh.NvkShard.new_unique_id(), 0, H, KV)
+        st = Stream()
+        try:
+            shard.set_gather_mode([shard.GATHER_AUTO, shard.GATHER_OVERLAPPED, shard.GATHER_INLINE][int(rng.integers(0, 3))])
+            q = work.q()
+            qd, td, cd = DeviceArray(q), DeviceArray(work.block_tables), DeviceArray(ctx)
+            outs = [DeviceArray(np.full_like(q, np.nan)) for _ in range(2)]
+            gath = [DeviceArray(np.full((1,) + q.shape, np.nan, np.float32)) for _ in range(2)]
+            got = []
+            for layer in range(L):
+                b = layer % 2
+                shard.decode_gather(pool, layer, n, qd, td, work.max_blocks, cd, work.max_ctx, outs[b], gath[b], b, flags, chunk,
+                                    compute_stream=st)
+                if layer > 0:
+                    shard.wait_gather((layer - 1) % 2, st)
+                    shard.wait_gather((layer - 1) % 2)
+                    got.append(gath[(layer - 1) % 2].numpy().copy())
+            shard.wait_gather((L - 1) % 2)
+            got.append(gath[(L - 1) % 2].numpy().copy())
+            st.synchronize()
+            for layer in range(L):
+                want = nv.decode(pool, layer, q, work.block_tables, ctx, flags, chunk)
+                assert np.isfinite(want).all() and np.array_equal(got[layer][0].view(np.uint32), want.view(np.uint32)), \
+                    f"{what}: layer-call {layer}"
+        finally:
+            shard.close()
+            st.close()
+
+
 def plan_case(seed):
     """A model step's use of decode plans (nvk_plan_build once per step, nvk_decode_planned per layer), over several
     steps of a batch whose sequences grow by a token, finish and join: each step the plan is rebuilt -- or, when the

@@ -6,7 +6,7 @@ path (an allocation, a device-wide wait); that used to invalidate the recording 
 -- against the checker's LlamaModel::forward (include/core/model.hpp:150-247)."""
 import pytest
 
-from fuzz_cases import decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, plan_case, pool_ops_case, prefill_long_case, projection_case
+from fuzz_cases import decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, plan_case, pool_ops_case, prefill_long_case, projection_case, shard_one_rank_case
 
 pytestmark = pytest.mark.gpu
 
@@ -99,3 +99,8 @@ def test_pool_fill_and_read_entry_points_in_random_order(seed):
 @pytest.mark.parametrize("seed", range(100, 130))
 def test_decode_plans_over_the_steps_of_a_batch(seed):
     plan_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(100, 108))
+def test_shard_entry_points_on_a_one_rank_communicator(seed):
+    shard_one_rank_case(seed)
