@@ -19,14 +19,15 @@ args = ap.parse_args()
 
 import test_gpu_attention as ta  # noqa: E402
 import test_gpu_prefill as tp  # noqa: E402
-from fuzz_cases import model_case  # noqa: E402
+from fuzz_cases import dropin_case, dropin_contiguous_case, model_case, pool_ops_case  # noqa: E402
 
 # (sweeps whose every device call goes through the library: host arrays in, host arrays out.  The projection and no-alloc
 #  sweeps, and the merge sweep, allocate and copy through the HIP runtime directly (tests/hipmem.py), on the null stream; ROCm 7.2 refuses such
 #  calls while ANY stream of the process records a graph, which is outside the library's gate -- INTEGRATION.md.)
 KINDS = [("decode", ta.test_random_geometry_batches_against_checker),
          ("prefill", tp.test_random_geometry_prefill_against_checker), ("model", model_case),
-         ("model, fewer blocks", lambda seed: model_case(seed, scarce=True))]
+         ("model, fewer blocks", lambda seed: model_case(seed, scarce=True)),
+         ("drop-in, host slabs", dropin_case), ("drop-in, contiguous", dropin_contiguous_case), ("pool", pool_ops_case)]
 done, fails, lock = {k: 0 for k, _ in KINDS}, [], threading.Lock()
 t_end = time.perf_counter() + args.minutes * 60
 
