@@ -65,6 +65,56 @@ def projection_case(seed):
             close(o.numpy(), a @ w.astype(np.float64).T, tag)
 
 
+_CLI_DIR = None
+
+
+def cli_case(seed):
+    """nvk_run (the reference's command line over the library) on a random request file -- prompts of random words and
+    bytes, token limits, JSON fields in any order with fields it must ignore -- at a random batch size, on one model or
+    sequence-sharded over two or three standing on GPU 0: every request prints exactly the text the Python mirror
+    (LlamaModel + Tokenizer over the same C ABI) generates for it alone."""
+    import json
+    import subprocess
+    import tempfile
+
+    import test_cli as tc
+    from golden_defs import write_checkpoint, write_tokenizer
+
+    global _CLI_DIR
+    if _CLI_DIR is None:
+        _CLI_DIR = tempfile.mkdtemp(prefix="nvk_cli_fuzz_")
+        write_checkpoint(os.path.join(_CLI_DIR, "model.bin"), tc.SPEC)
+        write_tokenizer(os.path.join(_CLI_DIR, "tokenizer.bin"), tc.SPEC["vocab_size"])
+    rng = np.random.default_rng(seed)
+    words = ["once", "upon", "a", "time", "the", "theory", "of", "thing", "hello", "inn", "ant", "hen", "and", "in", "an", "é", "x.", "?!"]
+    reqs = []
+    for _ in range(int(rng.integers(1, 7))):
+        prompt = " ".join(rng.choice(words, size=int(rng.integers(1, 9))).tolist())
+        fields = [("prompt", prompt), ("temperature", 0.0), ("max_tokens", int(rng.integers(1, 40)))]
+        if rng.random() < 0.5:
+            fields.append(("top_p", 0.9))
+        if rng.random() < 0.3:
+            fields.append(("extra", {"ignored": [1, {"deep": None}], "s": "\"quoted\" \\ text"}))
+        rng.shuffle(fields)
+        reqs.append(dict((k, v) for k, v in fields))
+    path = os.path.join(_CLI_DIR, f"reqs{seed}.json")
+    with open(path, "w") as fh:
+        json.dump({"name": f"fuzz{seed}", "requests": reqs}, fh, indent=int(rng.integers(0, 3)) or None)
+    batch = str(int(rng.integers(1, 6)))
+    sharding = [(), ("--devices", "0,0"), ("--devices", "0,0,0")][int(rng.integers(0, 3))]
+    what = f"seed {seed}: {len(reqs)} requests, -b {batch} {' '.join(sharding)}"
+    r = subprocess.run([tc.CLI, _CLI_DIR, "--input-json", path, "-b", batch, *sharding], capture_output=True, timeout=120)
+    os.remove(path)
+    assert r.returncode == 0, f"{what}: exit status {r.returncode}: {r.stderr[-300:]!r}"
+    parts = (b"\n" + r.stdout).split(b"\n[request ")[1:]
+    assert parts and parts[-1].endswith(b"\n"), f"{what}: output {r.stdout[:200]!r}"
+    parts[-1] = parts[-1][:-1]
+    got = {int(part.split(b"] ", 1)[0]): part.split(b"] ", 1)[1] for part in parts}
+    for i, rq in enumerate(reqs):
+        want = rq["prompt"].encode() + tc.expected_text(nv, _CLI_DIR, rq["prompt"], rq["max_tokens"], True)
+        assert got.get(i) == want, f"{what}: request {i} {rq['prompt']!r}: printed {got.get(i)!r}, expected {want!r}"
+
+
 def shard_one_rank_case(seed):
     """nvk_shard_* on a communicator of one rank (all a one-GPU box can form; the head slicing at world 2 and 4 is covered
     on CPU over gloo): random geometry, batch and mode, both places the collective can run, the two-buffer protocol over

@@ -6,7 +6,7 @@ path (an allocation, a device-wide wait); that used to invalidate the recording 
 -- against the checker's LlamaModel::forward (include/core/model.hpp:150-247)."""
 import pytest
 
-from fuzz_cases import decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, plan_case, pool_ops_case, prefill_long_case, projection_case, shard_one_rank_case
+from fuzz_cases import cli_case, decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, plan_case, pool_ops_case, prefill_long_case, projection_case, shard_one_rank_case
 
 pytestmark = pytest.mark.gpu
 
@@ -104,3 +104,16 @@ def test_decode_plans_over_the_steps_of_a_batch(seed):
 @pytest.mark.parametrize("seed", range(100, 108))
 def test_shard_entry_points_on_a_one_rank_communicator(seed):
     shard_one_rank_case(seed)
+
+
+@pytest.mark.parametrize("seed", [100, 109, 122, 124, 127, 130, 132, 146])
+def test_command_line_on_random_request_files(seed):
+    """(seeds 109 ... 146: files whose generated text holds the byte 0x00, which nvk_run used to print as the end of a C
+    string; the reference prints std::strings, runner.hpp:51)"""
+    import os
+
+    import test_cli
+
+    if not os.path.exists(test_cli.CLI):
+        pytest.skip("nano_vllm_amd/nvk_run not built (make cli)")
+    cli_case(seed)

@@ -414,7 +414,7 @@ int main(int argc, char **argv)
     long long            total_generated = 0, total_prompt = 0, steps_run = 0;
     const bool           single = input_json.empty();
     if (single)
-        printf("\n%s", prompt.c_str()), fflush(stdout); // runner.hpp:37
+        fputc('\n', stdout), fwrite(prompt.data(), 1, prompt.size(), stdout), fflush(stdout); // runner.hpp:37
     const auto t0 = std::chrono::high_resolution_clock::now();
     while (!running.empty() || next_request < requests.size()) {
         // admission (Scheduler::schedule: fill up to max_batch_size, scheduler.hpp:66-103)
@@ -463,7 +463,8 @@ int main(int argc, char **argv)
             const std::string piece = piece_of(tok, next[k]);
             r.text += piece;
             if (single)
-                fputs(piece.c_str(), stdout), fflush(stdout);
+                fwrite(piece.data(), 1, piece.size(), stdout), fflush(stdout); // (as std::cout << std::string, runner.hpp:51:
+                                                                               //  a piece may be the byte 0x00, which a C string ends at)
             const int len = nvk_model_group_request_len(model, r.id);
             // request_processor.hpp:55-77: max_tokens, max_seq_len, EOS (2)
             if (r.generated >= requests[(size_t)r.id].max_tokens || len >= cfg[6] || (!single && next[k] == 2)) // runner.hpp:48-57 has no EOS stop
@@ -473,7 +474,13 @@ int main(int argc, char **argv)
         for (int i : done) {
             Running &r = running[(size_t)i];
             if (!single)
-                printf("[request %d] %s%s\n", r.id, requests[(size_t)r.id].prompt.c_str(), r.text.c_str());
+            {
+                const std::string &prompt = requests[(size_t)r.id].prompt;
+                printf("[request %d] ", r.id);
+                fwrite(prompt.data(), 1, prompt.size(), stdout);
+                fwrite(r.text.data(), 1, r.text.size(), stdout); // (whole: generated bytes include 0x00)
+                fputc('\n', stdout);
+            }
             NVK_OR_DIE(nvk_model_group_finish_request(model, r.id));
             running.erase(running.begin() + i);
         }

@@ -23,7 +23,7 @@ import test_gpu_attention as ta  # noqa: E402
 import test_gpu_fused_merge as tm  # noqa: E402
 import test_gpu_prefill as tp  # noqa: E402
 
-from fuzz_cases import decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, plan_case, pool_ops_case, prefill_long_case, projection_case, shard_one_rank_case  # noqa: E402
+from fuzz_cases import cli_case, decode_large_case, dropin_case, dropin_contiguous_case, model_case, noalloc_case, plan_case, pool_ops_case, prefill_long_case, projection_case, shard_one_rank_case  # noqa: E402
 
 SWEEPS = [
     ("model: random checkpoints, batches", model_case),
@@ -33,6 +33,7 @@ SWEEPS = [
     ("pool: fill and read entry points", pool_ops_case),
     ("decode: plans over the steps of a batch", plan_case),
     ("shard: one-rank communicator", shard_one_rank_case),
+    ("nvk_run: request files", cli_case),
     ("drop-in: host slabs, both policies", dropin_case),
     ("drop-in: contiguous cache", dropin_contiguous_case),
     ("decode: the no-alloc entry point", noalloc_case),
